@@ -1,0 +1,153 @@
+"""CPU: the oracle restatements against the golden vectors produced by the reference's own
+NumPy functions (tests/golden/make_goldens.py) and the reference's committed fixtures."""
+import os
+
+import numpy as np
+import pytest
+
+from gsaj import synthetic as syn
+from oracle import dense_oracle as dor
+from oracle import oracle as orc
+
+DENSE = ["dense_N1_64x48.npz", "dense_N15_64x48.npz", "dense_N15_64x48_ortho.npz", "dense_N64_64x48.npz",
+         "dense_N15_640x480.npz"]
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _cam(g):
+    return syn.make_camera(g["w2c"], W=int(g["W"]), H=int(g["H"]), fx=float(g["fx"]), fy=float(g["fy"]),
+                           cx=float(g["cx"]), cy=float(g["cy"]))
+
+
+def test_kat1_printed_values(golden_dir):
+    """KAT-1 (3DGS_Analytical_Jacobian.ipynb cell 7): printed to 8 digits."""
+    g = _load(golden_dir, "kat_pose_jacobian.npz")
+    dmu, dcov = dor.pose_jacobians(g["T_cw"][0], g["mu_w"][0], g["Sigma_w"][0])
+    want_mu = np.array([[.19549196, 0, -.14144915, -.45030336, 1.52353159, -.62234864],
+                        [0, .19549196, -.12166415, -1.38731783, .45030336, .72355483]])
+    assert np.allclose(dmu, want_mu, atol=5e-8)
+    assert np.allclose(dcov[0], [.01702372, 0, -.01534148, -.00442592, .02238401, .00718759], atol=5e-8)
+    assert np.allclose(dcov[1], [.01745774, .00851186, -.01652386, -.03104707, -.00298765, -.04444839], atol=5e-8)
+    assert np.allclose(dcov[2], dcov[1], atol=1e-12)
+    assert np.allclose(dcov[3], [0, .03491547, -.04213209, -.12990266, .07104051, -.00718759], atol=5e-8)
+
+
+def test_pose_jacobian_vs_reference_function(golden_dir):
+    g = _load(golden_dir, "kat_pose_jacobian.npz")
+    for k in range(g["T_cw"].shape[0]):
+        dmu, dcov = dor.pose_jacobians(g["T_cw"][k], g["mu_w"][k], g["Sigma_w"][k])
+        assert np.allclose(dmu, g["dmu"][k], rtol=1e-10, atol=1e-12), k
+        assert np.allclose(dcov, g["dcov"][k], rtol=1e-9, atol=1e-11), k
+
+
+def test_kat2_oracle_values(golden_dir):
+    g = _load(golden_dir, "kat_pose_jacobian.npz")
+    dmu, dcov = dor.pose_jacobians(g["T_cw"][1], g["mu_w"][1], g["Sigma_w"][1])
+    assert np.allclose(dmu, [[.2, 0, -.12, -.48, 1.36, -.8], [0, .2, -.16, -1.64, .48, .6]], atol=1e-12)
+    assert np.allclose(dcov[0], [.0384, 0, -.03328, -.08512, .06144, -.0736], atol=1e-12)
+    assert np.allclose(dcov[3], [0, .0352, -.05632, -.22528, .14336, .0736], atol=1e-12)
+
+
+def test_naive_loop_golden(golden_dir):
+    """Loss_Derivative_wrt_mu_and_cov.compute_gradients_2D (the O(HWN^2) loop)."""
+    g = _load(golden_dir, "naive_N4_12x9.npz")
+    order = np.argsort(g["depth"], kind="stable")
+    mu, S, z, c = dor.dense_backward(g["mean_2D"][order], g["cov_2D"][order], g["color"][order], g["depth"][order],
+                                     g["alpha"][order], g["seed_color"], g["seed_depth"])[:4]
+    inv = np.argsort(order)
+    assert np.allclose(mu[inv], g["grad_mu"], rtol=2e-4, atol=2e-5)
+    assert np.allclose(S[inv], g["grad_Sigma"], rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("name", DENSE)
+def test_dense_projection_golden(golden_dir, name):
+    g = _load(golden_dir, name)
+    cam = _cam(g)
+    m2, c2, dep = dor.project_gaussians(g["means3D"], g["cov3D6"], cam["w2c"], cam["fx"], cam["fy"], cam["cx"], cam["cy"],
+                                        cam["W"], cam["H"])
+    order = g["order"]
+    assert np.array_equal(np.argsort(dep, kind="stable"), order)
+    assert np.allclose(m2[order], g["mean_2D"], rtol=1e-5, atol=2e-4)
+    assert np.allclose(c2[order], g["cov_2D"], rtol=2e-5, atol=1e-5)
+    assert np.allclose(dep[order], g["depth"], rtol=1e-6, atol=1e-6)
+    dirs = dor.view_dirs(g["means3D"].astype(np.float64), cam["campos"].astype(np.float64))
+    col, raw = dor.colors_from_sh(g["shs"].astype(np.float64), dirs, 3)
+    assert np.allclose(col[order], g["color"], rtol=1e-9, atol=1e-10)
+    assert np.allclose(raw, g["color_raw"], rtol=1e-9, atol=1e-10)
+
+
+@pytest.mark.parametrize("name", DENSE)
+def test_dense_backward_golden(golden_dir, name):
+    g = _load(golden_dir, name)
+    o = g["order"]
+    mu, S, z, c = dor.dense_backward(g["mean_2D"], g["cov_2D"], g["color"], g["depth"], g["opacities"][o, 0],
+                                     g["seed_color"].astype(np.float32), g["seed_depth"].astype(np.float32))
+    for got, want in ((mu, g["grad_mu"]), (S, g["grad_Sigma"]), (z, g["grad_depth"]), (c, g["grad_color"])):
+        scale = np.abs(want).max() + 1e-12
+        assert np.abs(got - want).max() <= 2e-4 * scale, (name, np.abs(got - want).max(), scale)
+
+
+@pytest.mark.parametrize("name", DENSE)
+def test_dense_tau_golden(golden_dir, name):
+    g = _load(golden_dir, name)
+    cam = _cam(g)
+    N = int(g["N"])
+    xyz_h = np.concatenate([g["means3D"].astype(np.float64), np.ones((N, 1))], 1)
+    dmu, dcov = dor.pose_jacobians_all(xyz_h, g["cov3D6"], cam["w2c"], cam["fx"], cam["fy"], cam["W"], cam["H"])
+    assert np.allclose(dmu, g["dmu_dtau"], rtol=1e-9, atol=1e-11)
+    assert np.allclose(dcov, g["dcov_dtau"], rtol=1e-8, atol=1e-9)
+    tau, _ = dor.assemble_dL_dtau(g["order"], g["grad_mu"], g["grad_Sigma"], g["grad_depth"], g["grad_color"], dmu, dcov,
+                                  g["means3D"], cam["w2c"], cam["campos"], g["shs"], 3)
+    assert np.allclose(tau, g["dL_dtau"], rtol=1e-8, atol=1e-8 * np.abs(g["dL_dtau"]).max())
+
+
+def test_orphan_goldens_structure(golden_dir):
+    """Jacob_test_result/*.npy of the reference: inputs are missing blobs, so they only pin
+    shapes, dtypes, ordering conventions and magnitudes."""
+    d = os.path.join(golden_dir, "reference_fixtures")
+    mu = np.load(os.path.join(d, "grad_mu_I_pixel.npy"))
+    S = np.load(os.path.join(d, "grad_Sigma_I_pixel.npy"))
+    z = np.load(os.path.join(d, "grad_depth_per_gaussian.npy"))
+    tau = np.load(os.path.join(d, "dL_dtau.npy"))
+    assert mu.shape == (15, 2) and mu.dtype == np.float32
+    assert S.shape == (15, 2, 2) and S.dtype == np.float32
+    assert z.shape == (15,) and z.dtype == np.float32 and (z < 0).all()
+    assert tau.shape == (6,) and tau.dtype == np.float64
+    assert np.abs(S[:, 0, 1] - S[:, 1, 0]).max() < 1e-6
+    # our dense oracle produces the same layout on a 15-Gaussian scene
+    g = _load(golden_dir, "dense_N15_64x48.npz")
+    o = g["order"]
+    mu2, S2, z2, _ = dor.dense_backward(g["mean_2D"], g["cov_2D"], g["color"], g["depth"], g["opacities"][o, 0],
+                                        g["seed_color"].astype(np.float32), g["seed_depth"].astype(np.float32))
+    assert mu2.shape == mu.shape and mu2.dtype == mu.dtype and S2.shape == S.shape and z2.shape == z.shape
+    w2c = np.loadtxt(os.path.join(d, "w2c_gt.txt"))
+    tn = np.loadtxt(os.path.join(d, "T_noise.txt"))
+    assert np.allclose(w2c, syn.W2C_GT) and np.allclose(tn, syn.T_NOISE)
+    cam = syn.fixture_camera(noisy=True)
+    assert abs(cam["tanfovx"] - 0.554113) < 1e-6 and abs(cam["tanfovy"] - 0.415584) < 1e-6
+    assert np.allclose(cam["campos"], [2.3987, -0.0471, 1.0625], atol=2e-4)  # Jacobian_test.ipynb cell 7
+
+
+@pytest.mark.parametrize("name", ["dense_N15_64x48.npz", "dense_N64_64x48.npz", "dense_N15_640x480.npz"])
+def test_tiled_oracle_preprocess_vs_reference_substeps(golden_dir, name):
+    """The C (rasteriser-semantics) oracle shares its projection sub-steps with the reference's
+    NumPy path: compute_cov2d, ndc2Pix, SH colours, view-space depth."""
+    g = _load(golden_dir, name)
+    cam = _cam(g)
+    out, st = orc.forward(g["means3D"], g["opacities"], cam["viewmatrix"], cam["projmatrix"], cam["campos"],
+                          cam["tanfovx"], cam["tanfovy"], cam["W"], cam["H"], np.zeros(3), shs=g["shs"],
+                          scales=g["scales"], rotations=g["rotations"], sh_degree=3)
+    o = g["order"]
+    vis = st["radii"][o] > 0
+    assert vis.sum() >= max(1, int(0.5 * len(o)))
+    co = st["conic_opacity"][o][vis].astype(np.float64)
+    con = np.stack([np.stack([co[:, 0], co[:, 1]], -1), np.stack([co[:, 1], co[:, 2]], -1)], -2)
+    cov = np.linalg.inv(con)
+    assert np.allclose(cov, g["cov_2D"][vis], rtol=2e-4, atol=2e-4)
+    assert np.allclose(st["means2D"][o][vis], g["mean_2D"][vis], rtol=1e-5, atol=2e-3)
+    assert np.allclose(st["depths"][o][vis], g["depth"][vis], rtol=1e-5)
+    assert np.allclose(st["rgb"][o][vis], g["color"][vis], rtol=1e-4, atol=1e-5)
+    assert np.allclose(st["cov3D"], g["cov3D6"], rtol=1e-4, atol=1e-7)
