@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: forward splat + analytical-Jacobian backward of one 640x480 frame
+(BASELINE.json metric: Gaussian-pixel interactions / second, fwd + Jacobian).
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one frame per rank: preprocess -> (tile, depth) sort ->
+composite -> reverse composite -> per-Gaussian backward incl. dL/dtau, all through the C ABI of
+libgsaj_hip.so, with every input already resident in HBM.  For N > 1 every rank owns one keyframe
+of the same (replicated) Gaussian map (weak scaling) and the step ends with the RCCL all-reduce of
+the per-Gaussian gradient bucket and the all-gather of the per-keyframe dL/dtau.
+An interaction = one (pixel, Gaussian) pair the compositor visits: I = sum over pixels of n_contrib
+(SURVEY 8d).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "gs-slam-analytica_jacobian_amd")
+for _p in (ROOT, PKG):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FLOP_FWD, FLOP_BWD = 24.0, 87.0  # fp32 flop per interaction (+ 1 exp fwd, 1 exp + 1 rcp bwd)
+PEAK_FP32_TFLOPS = 157.3         # MI355X fp32 vector = fp32 MFMA dense peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg5"])
+    ap.add_argument("--sh-degree", type=int, default=3)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg (rank 0, N=1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU product path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+
+    from gsaj import synthetic as syn
+    from gsaj import keyframe_shard as ks
+    from gsaj.rasterizer import FrameContext, profile_stages
+
+    cam0, sc = syn.config_scene(a.workload)
+    if world > 1:  # one keyframe per rank, on a 0.5 m arc around the cfg camera (cfg4-style window)
+        cam = syn.keyframe_cameras(world, W=cam0["W"], H=cam0["H"], fx=cam0["fx"], fy=cam0["fy"], cx=cam0["cx"],
+                                   cy=cam0["cy"])[rank]
+    else:
+        cam = cam0
+    P, W, H = sc["means3D"].shape[0], cam["W"], cam["H"]
+    M = sc["shs"].shape[1]
+    deg = min(a.sh_degree, int(round(M ** 0.5)) - 1)
+    t = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32, device=dev)  # noqa: E731
+    means, opac, shs, scales, rots = t(sc["means3D"]), t(sc["opacities"]), t(sc["shs"]), t(sc["scales"]), t(sc["rotations"])
+    view, proj, proj_raw, campos = t(cam["viewmatrix"]), t(cam["projmatrix"]), t(cam["projmatrix_raw"]), t(cam["campos"])
+    bg = torch.zeros(3, device=dev)
+    rng = np.random.default_rng(1234 + rank)
+    dLc = t(rng.normal(size=(3, H, W)) / (3 * H * W))  # pixel-gradient seeds, resident in HBM
+    dLd = t(rng.normal(size=(1, H, W)) / (H * W))
+    ctx = FrameContext(P, W, H, M, dev)
+    tau_all = None
+
+    def step():
+        nonlocal tau_all
+        ctx.forward(bg, means, opac, view, proj, campos, cam["tanfovx"], cam["tanfovy"], sh_degree=deg, shs=shs,
+                    scales=scales, rotations=rots)
+        g = ctx.backward(bg, means, view, proj, proj_raw, campos, cam["tanfovx"], cam["tanfovy"], dLc, dLd,
+                         sh_degree=deg, shs=shs, scales=scales, rotations=rots)
+        if world > 1:
+            ks.allreduce_gaussian_grads(ctx.bucket)
+            tau_all = ks.gather_pose_grads(g["tau_sum"].view(1, 6), world)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    inter = ctx.interactions()
+    R = ctx.R
+
+    # same K steps again with every kernel bracketed by HIP events on its launch stream
+    fence()
+    with profile_stages(max_records=a.steps * 16) as prof:
+        for _ in range(a.steps):
+            step()
+    fence()
+
+    stats = torch.tensor([elapsed, float(inter), float(R)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = stats[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tot = stats[1:].clone()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        elapsed, inter_total, R_total = float(tmax[0]), float(tot[0]), float(tot[1])
+    else:
+        inter_total, R_total = float(inter), float(R)
+
+    if rank == 0:
+        ms_step = 1e3 * elapsed / a.steps
+        value = inter_total * a.steps / elapsed
+        n = max(prof.launches["render_bwd"], 1)
+        t_bwd = prof.ms["render_bwd"] / n * 1e-3
+        t_fwd = prof.ms["render_fwd"] / max(prof.launches["render_fwd"], 1) * 1e-3
+        t_gb = prof.ms["gaussian_bwd"] / max(prof.launches["gaussian_bwd"], 1) * 1e-3
+        ach = FLOP_BWD * inter / t_bwd / 1e12 if t_bwd > 0 else 0.0
+        shf = 3 * M * 4
+        gb_bytes = P * ((12 + 24 + 4 + 16 + 12 + shf + 12 + 16 + 3) + (12 + 16 + 4 + 12 + 4 + 12 + 24 + shf + 12 + 16)) + R * (48 + 4)
+        out = {
+            "metric": "Gaussian-pixel interactions/sec (fwd+Jacobian), 640x480",
+            "value": value, "unit": "interactions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %d Gaussians (SH degree %d, %d coeffs), %dx%d, forward splat + analytical "
+                                   "Jacobian backward (dL/dmu, dL/dSigma->conic, per-Gaussian grads, dL/dtau)"
+                                   % (a.workload, P, deg, M, W, H),
+                       "interactions_per_frame_rank0": inter, "num_rendered_rank0": R,
+                       "parallelism": "1 keyframe per GPU, all-reduce of %d-float grad bucket + all-gather of dL/dtau"
+                                      % ctx.bucket.numel() if world > 1 else "single GPU"},
+            "roofline": {"bound": "mfma", "kernel": "k_render_bwd", "achieved": ach, "peak": PEAK_FP32_TFLOPS,
+                         "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS, "traffic": None,
+                         "note": "fp32 VALU/transcendental-bound reverse compositor: 87 fp32 flop x interactions per "
+                                 "launch / HIP-event launch time; peak = fp32 vector = fp32 MFMA dense peak",
+                         "avg_launch_ms": t_bwd * 1e3},
+            "roofline_other": {
+                "k_render_fwd": {"bound": "mfma", "achieved": FLOP_FWD * inter / t_fwd / 1e12 if t_fwd > 0 else 0.0,
+                                 "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "avg_launch_ms": t_fwd * 1e3},
+                "k_gaussian_bwd": {"bound": "hbm", "achieved": gb_bytes / t_gb / 1e9 if t_gb > 0 else 0.0,
+                                   "peak": PEAK_HBM_GBS, "unit": "GB/s", "avg_launch_ms": t_gb * 1e3,
+                                   "algorithmic_bytes": gb_bytes}},
+            "stage_ms_per_step": {k: v / a.steps for k, v in prof.ms.items() if prof.launches[k]},
+        }
+        for k in ("k_render_fwd", "k_gaussian_bwd"):
+            o = out["roofline_other"][k]
+            o["frac"] = o["achieved"] / o["peak"]
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cam, sc, deg, a.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cam, sc, deg, budget_s):
+    """The CPU oracle (a C port of the reference's rasteriser semantics, single thread) on whole
+    frames of the same workload, repeated until the budget is spent."""
+    from oracle import oracle as orc
+
+    W, H = cam["W"], cam["H"]
+    rng = np.random.default_rng(1234)
+    dLc = (rng.normal(size=(3, H, W)) / (3 * H * W)).astype(np.float32)
+    dLd = (rng.normal(size=(1, H, W)) / (H * W)).astype(np.float32)
+    reps, inter, t0 = 0, 0, time.perf_counter()
+    while True:
+        out, st = orc.forward(sc["means3D"], sc["opacities"], cam["viewmatrix"], cam["projmatrix"], cam["campos"],
+                              cam["tanfovx"], cam["tanfovy"], W, H, np.zeros(3, np.float32), shs=sc["shs"],
+                              scales=sc["scales"], rotations=sc["rotations"], sh_degree=deg)
+        orc.backward(st, dLc, dLd, cam["projmatrix_raw"])
+        reps += 1
+        inter += st["interactions"]
+        el = time.perf_counter() - t0
+        if el >= budget_s or reps >= 8:
+            break
+    return {"value": inter / el, "unit": "interactions/s", "cores": 1, "kind": "port",
+            "sample": "%d full frame(s) of the same workload (forward + backward), %.1f s on 1 of %d host cores"
+                      % (reps, el, os.cpu_count())}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,303 @@
+// api.hip -- extern "C" entry points of libgsaj_hip.so (see include/gsaj.h).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "gsaj_common.h"
+
+static thread_local char g_err[512] = "";
+
+void gsaj_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+static uint32_t higher_msb(uint32_t n) {  // number of bits needed for tile ids (rasterizer_impl.cu:35-50)
+  uint32_t bits = 0;
+  while ((n >> bits) != 0 && bits < 32) bits++;
+  return bits;
+}
+
+// ---- event-based per-stage profiler ------------------------------------------------------------
+struct ProfRec { int stage; hipEvent_t a, b; };
+static ProfRec *g_prof = nullptr;
+static int g_prof_cap = 0, g_prof_n = 0, g_prof_open = -1;
+
+void gsaj_prof_mark(int stage, int is_stop, hipStream_t s) {
+  if (!g_prof) return;
+  if (!is_stop) {
+    if (g_prof_n >= g_prof_cap) { g_prof_open = -1; return; }
+    g_prof_open = g_prof_n++;
+    g_prof[g_prof_open].stage = stage;
+    (void)hipEventRecord(g_prof[g_prof_open].a, s);
+  } else if (g_prof_open >= 0) {
+    (void)hipEventRecord(g_prof[g_prof_open].b, s);
+    g_prof_open = -1;
+  }
+}
+
+extern "C" {
+
+int gsaj_profile_begin(int max_records) {
+  if (g_prof || max_records <= 0) {
+    gsaj_set_error("gsaj_profile_begin: already active or bad size");
+    return GSAJ_ERR_INVALID_ARGUMENT;
+  }
+  g_prof = new ProfRec[max_records];
+  for (int i = 0; i < max_records; i++) {
+    GSAJ_HIP_CHECK(hipEventCreate(&g_prof[i].a));
+    GSAJ_HIP_CHECK(hipEventCreate(&g_prof[i].b));
+  }
+  g_prof_cap = max_records;
+  g_prof_n = 0;
+  g_prof_open = -1;
+  return GSAJ_OK;
+}
+
+int gsaj_profile_end(float *stage_ms, int *stage_launches) {
+  if (!g_prof || !stage_ms || !stage_launches) {
+    gsaj_set_error("gsaj_profile_end: not active");
+    return GSAJ_ERR_INVALID_ARGUMENT;
+  }
+  GSAJ_HIP_CHECK(hipDeviceSynchronize());
+  for (int i = 0; i < ST_COUNT; i++) { stage_ms[i] = 0.f; stage_launches[i] = 0; }
+  for (int i = 0; i < g_prof_n; i++) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, g_prof[i].a, g_prof[i].b) == hipSuccess) {
+      stage_ms[g_prof[i].stage] += ms;
+      stage_launches[g_prof[i].stage] += 1;
+    }
+  }
+  for (int i = 0; i < g_prof_cap; i++) { (void)hipEventDestroy(g_prof[i].a); (void)hipEventDestroy(g_prof[i].b); }
+  delete[] g_prof;
+  g_prof = nullptr;
+  g_prof_cap = g_prof_n = 0;
+  return GSAJ_OK;
+}
+
+const char *gsaj_last_error(void) { return g_err; }
+int gsaj_version(void) { return 100; }
+
+size_t gsaj_geom_workspace_bytes(int P) { return geom_carve(nullptr, (size_t)(P > 0 ? P : 0), nullptr) + 256; }
+size_t gsaj_image_workspace_bytes(int W, int H) { return image_carve(nullptr, W, H, nullptr) + 256; }
+size_t gsaj_binning_workspace_bytes(int R) {
+  return bin_carve(nullptr, (size_t)(R > 0 ? R : 0), gsaj_sort_temp_bytes(R), nullptr) + 256;
+}
+
+static char *align_base(void *p) { return reinterpret_cast<char *>(gsaj_align(reinterpret_cast<size_t>(p))); }
+
+int gsaj_forward_preprocess(int P, int D, int M, int W, int H, const float *means3D, const float *shs,
+                            const float *colors_precomp, const float *opacities, const float *scales,
+                            float scale_modifier, const float *rotations, const float *cov3D_precomp,
+                            const float *viewmatrix, const float *projmatrix, const float *campos, float tanfovx,
+                            float tanfovy, int prefiltered, int *radii, void *geom_ws, void *stream) {
+  if (P <= 0 || W <= 0 || H <= 0 || !means3D || !opacities || !viewmatrix || !projmatrix || !geom_ws) {
+    gsaj_set_error("gsaj_forward_preprocess: invalid argument (P=%d W=%d H=%d)", P, W, H);
+    return GSAJ_ERR_INVALID_ARGUMENT;
+  }
+  if ((shs == nullptr) == (colors_precomp == nullptr)) {
+    gsaj_set_error("Please provide excatly one of either SHs or precomputed colors!");
+    return GSAJ_ERR_INVALID_ARGUMENT;
+  }
+  if (((scales == nullptr || rotations == nullptr) && cov3D_precomp == nullptr) ||
+      ((scales != nullptr || rotations != nullptr) && cov3D_precomp != nullptr)) {
+    gsaj_set_error("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+    return GSAJ_ERR_INVALID_ARGUMENT;
+  }
+  if (shs && (!campos || M <= 0 || D < 0 || (D + 1) * (D + 1) > M || D > 3)) {
+    gsaj_set_error("gsaj_forward_preprocess: SH degree %d needs %d coefficients, got M=%d", D, (D + 1) * (D + 1), M);
+    return GSAJ_ERR_INVALID_ARGUMENT;
+  }
+  GeomWS g;
+  geom_carve(align_base(geom_ws), (size_t)P, &g);
+  FwdParams p;
+  p.P = P; p.D = D; p.M = M; p.W = W; p.H = H;
+  p.means3D = means3D; p.shs = shs; p.colors_precomp = colors_precomp; p.opacities = opacities;
+  p.scales = scales; p.rotations = rotations; p.cov3D_precomp = cov3D_precomp;
+  p.viewmatrix = viewmatrix; p.projmatrix = projmatrix; p.campos = campos;
+  p.scale_modifier = scale_modifier; p.tanfovx = tanfovx; p.tanfovy = tanfovy;
+  p.focal_y = H / (2.0f * tanfovy);
+  p.focal_x = W / (2.0f * tanfovx);
+  p.prefiltered = prefiltered;
+  p.grid_x = (W + TILE - 1) / TILE; p.grid_y = (H + TILE - 1) / TILE;
+  return launch_preprocess(p, radii ? radii : g.internal_radii, g, (hipStream_t)stream);
+}
+
+int gsaj_forward_num_rendered(int P, const void *geom_ws, void *stream, int *num_rendered) {
+  if (P <= 0 || !geom_ws || !num_rendered) {
+    gsaj_set_error("gsaj_forward_num_rendered: invalid argument");
+    return GSAJ_ERR_INVALID_ARGUMENT;
+  }
+  GeomWS g;
+  geom_carve(align_base(const_cast<void *>(geom_ws)), (size_t)P, &g);
+  uint32_t host[2] = {0, 0};
+  GSAJ_HIP_CHECK(hipMemcpyAsync(host, g.counters, sizeof(host), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  GSAJ_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  *num_rendered = (int)host[0];
+  if (host[1] != 0) {
+    gsaj_set_error("Point is filtered although prefiltered is set. This shouldn't happen!");
+    return GSAJ_ERR_PREFILTERED_CULLED;
+  }
+  return GSAJ_OK;
+}
+
+int gsaj_forward_render(int P, int R, int W, int H, const float *bg, const float *colors_precomp, const int *radii,
+                        void *geom_ws, void *binning_ws, size_t binning_ws_bytes, void *image_ws, float *out_color,
+                        float *out_depth, float *out_opacity, int *n_touched, void *stream) {
+  if (P <= 0 || R < 0 || W <= 0 || H <= 0 || !bg || !geom_ws || !binning_ws || !image_ws || !out_color || !out_depth ||
+      !out_opacity || !n_touched) {
+    gsaj_set_error("gsaj_forward_render: invalid argument");
+    return GSAJ_ERR_INVALID_ARGUMENT;
+  }
+  const size_t need = gsaj_binning_workspace_bytes(R);
+  if (binning_ws_bytes < need) {
+    gsaj_set_error("binning workspace too small: have %zu bytes, need %zu for R=%d", binning_ws_bytes, need, R);
+    return GSAJ_ERR_WORKSPACE_TOO_SMALL;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  GeomWS g;
+  geom_carve(align_base(geom_ws), (size_t)P, &g);
+  ImageWS im;
+  image_carve(align_base(image_ws), W, H, &im);
+  BinWS b;
+  bin_carve(align_base(binning_ws), (size_t)R, gsaj_sort_temp_bytes(R), &b);
+  const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+  const int *rad = radii ? radii : g.internal_radii;
+  const float *features = colors_precomp ? colors_precomp : g.rgb;
+  int rc;
+  GSAJ_HIP_CHECK(hipMemsetAsync(n_touched, 0, sizeof(int) * (size_t)P, s));
+  if ((rc = launch_emit_keys(P, gx, gy, rad, g, b, s)) != GSAJ_OK) return rc;
+  if ((rc = launch_sort(R, 32 + (int)higher_msb((uint32_t)(gx * gy)), b, s)) != GSAJ_OK) return rc;
+  if ((rc = launch_ranges_and_records(P, R, gx, gy, rad, features, g, b, im, s)) != GSAJ_OK) return rc;
+  return launch_render_forward(W, H, gx, gy, bg, b, im, out_color, out_depth, out_opacity, n_touched, s);
+}
+
+int gsaj_rasterize_forward(int P, int D, int M, const float *bg, int W, int H, const float *means3D, const float *shs,
+                           const float *colors_precomp, const float *opacities, const float *scales,
+                           float scale_modifier, const float *rotations, const float *cov3D_precomp,
+                           const float *viewmatrix, const float *projmatrix, const float *campos, float tanfovx,
+                           float tanfovy, int prefiltered, float *out_color, float *out_depth, float *out_opacity,
+                           int *radii, int *n_touched, void *geom_ws, void *binning_ws, size_t binning_ws_bytes,
+                           void *image_ws, int *num_rendered_out, void *stream) {
+  int rc = gsaj_forward_preprocess(P, D, M, W, H, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
+                                   rotations, cov3D_precomp, viewmatrix, projmatrix, campos, tanfovx, tanfovy,
+                                   prefiltered, radii, geom_ws, stream);
+  if (rc != GSAJ_OK) return rc;
+  int R = 0;
+  rc = gsaj_forward_num_rendered(P, geom_ws, stream, &R);
+  if (num_rendered_out) *num_rendered_out = R;
+  if (rc != GSAJ_OK) return rc;
+  rc = gsaj_forward_render(P, R, W, H, bg, colors_precomp, radii, geom_ws, binning_ws, binning_ws_bytes, image_ws,
+                           out_color, out_depth, out_opacity, n_touched, stream);
+  return rc == GSAJ_OK ? R : rc;
+}
+
+int gsaj_rasterize_backward(int P, int D, int M, int R, const float *bg, int W, int H, const float *means3D,
+                            const float *shs, const float *colors_precomp, const float *scales, float scale_modifier,
+                            const float *rotations, const float *cov3D_precomp, const float *viewmatrix,
+                            const float *projmatrix, const float *projmatrix_raw, const float *campos, float tanfovx,
+                            float tanfovy, const int *radii, void *geom_ws, void *binning_ws, void *image_ws,
+                            const float *dL_dpix, const float *dL_dpix_depth, float *dL_dmean2D, float *dL_dconic,
+                            float *dL_dopacity, float *dL_dcolor, float *dL_ddepth, float *dL_dmean3D,
+                            float *dL_dcov3D, float *dL_dsh, float *dL_dscale, float *dL_drot, float *dL_dtau,
+                            float *dL_dtau_sum, void *stream) {
+  if (P <= 0 || R < 0 || W <= 0 || H <= 0 || !bg || !means3D || !viewmatrix || !projmatrix || !projmatrix_raw ||
+      !geom_ws || !binning_ws || !image_ws || !dL_dpix || !dL_dpix_depth || !dL_dmean2D || !dL_dconic ||
+      !dL_dopacity || !dL_dcolor || !dL_ddepth || !dL_dmean3D || !dL_dcov3D) {
+    gsaj_set_error("gsaj_rasterize_backward: invalid argument");
+    return GSAJ_ERR_INVALID_ARGUMENT;
+  }
+  if ((shs && (!dL_dsh || !campos)) || (scales && (!rotations || !dL_dscale || !dL_drot)) || (!scales && !cov3D_precomp)) {
+    gsaj_set_error("gsaj_rasterize_backward: missing gradient buffer for a provided input");
+    return GSAJ_ERR_INVALID_ARGUMENT;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  GeomWS g;
+  geom_carve(align_base(geom_ws), (size_t)P, &g);
+  ImageWS im;
+  image_carve(align_base(image_ws), W, H, &im);
+  BinWS b;
+  bin_carve(align_base(binning_ws), (size_t)R, gsaj_sort_temp_bytes(R), &b);
+  const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+  // zero-init of every accumulated / sparsely written output (rasterize_points.cu:175-185)
+  const size_t Pz = (size_t)P;
+  GSAJ_HIP_CHECK(hipMemsetAsync(dL_dmean2D, 0, sizeof(float) * 3 * Pz, s));
+  GSAJ_HIP_CHECK(hipMemsetAsync(dL_dconic, 0, sizeof(float) * 4 * Pz, s));
+  GSAJ_HIP_CHECK(hipMemsetAsync(dL_dopacity, 0, sizeof(float) * Pz, s));
+  GSAJ_HIP_CHECK(hipMemsetAsync(dL_dcolor, 0, sizeof(float) * 3 * Pz, s));
+  GSAJ_HIP_CHECK(hipMemsetAsync(dL_ddepth, 0, sizeof(float) * Pz, s));
+  GSAJ_HIP_CHECK(hipMemsetAsync(dL_dmean3D, 0, sizeof(float) * 3 * Pz, s));
+  GSAJ_HIP_CHECK(hipMemsetAsync(dL_dcov3D, 0, sizeof(float) * 6 * Pz, s));
+  if (dL_dsh && M > 0) GSAJ_HIP_CHECK(hipMemsetAsync(dL_dsh, 0, sizeof(float) * 3 * (size_t)M * Pz, s));
+  if (dL_dscale) GSAJ_HIP_CHECK(hipMemsetAsync(dL_dscale, 0, sizeof(float) * 3 * Pz, s));
+  if (dL_drot) GSAJ_HIP_CHECK(hipMemsetAsync(dL_drot, 0, sizeof(float) * 4 * Pz, s));
+  if (dL_dtau) GSAJ_HIP_CHECK(hipMemsetAsync(dL_dtau, 0, sizeof(float) * 6 * Pz, s));
+
+  int rc = launch_render_backward(R, W, H, gx, gy, bg, b, im, dL_dpix, dL_dpix_depth, s);
+  if (rc != GSAJ_OK) return rc;
+  BwdParams p;
+  p.P = P; p.D = D; p.M = M; p.W = W; p.H = H;
+  p.means3D = means3D; p.shs = shs; p.scales = scales; p.rotations = rotations;
+  p.cov3Ds = cov3D_precomp ? cov3D_precomp : g.cov3D;
+  p.viewmatrix = viewmatrix; p.projmatrix = projmatrix; p.projmatrix_raw = projmatrix_raw; p.campos = campos;
+  p.scale_modifier = scale_modifier; p.tanfovx = tanfovx; p.tanfovy = tanfovy;
+  p.focal_y = H / (2.0f * tanfovy);
+  p.focal_x = W / (2.0f * tanfovx);
+  p.grid_x = gx; p.grid_y = gy;
+  p.radii = radii ? radii : g.internal_radii;
+  p.dL_dmean2D = dL_dmean2D; p.dL_dconic = dL_dconic; p.dL_dopacity = dL_dopacity; p.dL_dcolor = dL_dcolor;
+  p.dL_ddepth = dL_ddepth; p.dL_dmean3D = dL_dmean3D; p.dL_dcov3D = dL_dcov3D; p.dL_dsh = dL_dsh;
+  p.dL_dscale = dL_dscale; p.dL_drot = dL_drot; p.dL_dtau = dL_dtau; p.dL_dtau_sum = dL_dtau_sum;
+  (void)colors_precomp;
+  return launch_gaussian_backward(p, g, b, s);
+}
+
+int gsaj_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix, uint8_t *present,
+                      void *stream) {
+  (void)projmatrix;  // the reference's test only uses the view-space depth (auxiliary.h:154)
+  if (P <= 0 || !means3D || !viewmatrix || !present) {
+    gsaj_set_error("gsaj_mark_visible: invalid argument");
+    return GSAJ_ERR_INVALID_ARGUMENT;
+  }
+  return launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream);
+}
+
+int gsaj_debug_export(int P, int R, int W, int H, const void *geom_ws, const void *binning_ws, const void *image_ws,
+                      float *means2D, float *depths, float *cov3D, float *conic_opacity, float *rgb, uint8_t *clamped,
+                      uint32_t *tiles_touched, uint32_t *point_list, uint32_t *ranges, float *final_T,
+                      uint32_t *n_contrib, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const size_t Pz = (size_t)P, N = (size_t)W * H;
+  const size_t tiles = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+#define CP(dst, src, bytes) \
+  if (dst) GSAJ_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s))
+  if (geom_ws) {
+    GeomWS g;
+    geom_carve(align_base(const_cast<void *>(geom_ws)), Pz, &g);
+    CP(means2D, g.means2D, sizeof(float2) * Pz);
+    CP(depths, g.depths, sizeof(float) * Pz);
+    CP(cov3D, g.cov3D, sizeof(float) * 6 * Pz);
+    CP(conic_opacity, g.conic_opacity, sizeof(float4) * Pz);
+    CP(rgb, g.rgb, sizeof(float) * 3 * Pz);
+    CP(clamped, g.clamped, 3 * Pz);
+    CP(tiles_touched, g.tiles_touched, sizeof(uint32_t) * Pz);
+  }
+  if (binning_ws && R > 0) {
+    BinWS b;
+    bin_carve(align_base(const_cast<void *>(binning_ws)), (size_t)R, gsaj_sort_temp_bytes(R), &b);
+    CP(point_list, b.point_list, sizeof(uint32_t) * (size_t)R);
+  }
+  if (image_ws) {
+    ImageWS im;
+    image_carve(align_base(const_cast<void *>(image_ws)), W, H, &im);
+    CP(ranges, im.ranges, sizeof(uint2) * tiles);
+    CP(final_T, im.final_T, sizeof(float) * N);
+    CP(n_contrib, im.n_contrib, sizeof(uint32_t) * N);
+  }
+#undef CP
+  return GSAJ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,325 @@
+// gaussian_bwd.hip -- fused per-Gaussian backward (gfx950): instance-gradient gather,
+// conic -> cov2D -> (cov3D, mean3D, tau), mean2D -> (mean3D, tau), depth -> (mean3D, tau),
+// colour -> (SH, mean3D, tau), cov3D -> (scale, rotation), and the reduction of dL/dtau.
+//
+// The reference runs computeCov2DCUDA (backward.cu:150-422), preprocessCUDA (:494-624, with
+// computeColorFromSH :21-145 and computeCov3D :426-489) as two kernels that `+=` into
+// dL_dmean3D / dL_dtau through global memory, then torch.sum over [P,6]
+// (diff_gaussian_rasterization/__init__.py:162).  Here one lane owns one Gaussian end to end:
+// it first sums the partial gradients of its (tile, Gaussian) instances in emission order
+// (deterministic -- replaces the float atomics of backward.cu:852-869), keeps every
+// intermediate in registers, writes each output once, and the 6 pose components are reduced
+// wave -> workgroup -> a fixed-order final pass.  HBM-bound streaming stage.
+#include "gsaj_common.h"
+
+__constant__ float bSH_C0 = 0.28209479177387814f;
+__constant__ float bSH_C1 = 0.4886025119029199f;
+__constant__ float bSH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f,
+                                0.5462742152960396f};
+__constant__ float bSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                                -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+
+__device__ __forceinline__ float3 dnormvdv(float3 v, float3 dv) {
+  const float sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
+  const float inv = 1.0f / sqrtf(sum2 * sum2 * sum2);
+  float3 o;
+  o.x = ((+sum2 - v.x * v.x) * dv.x - v.y * v.x * dv.y - v.z * v.x * dv.z) * inv;
+  o.y = (-v.x * v.y * dv.x + (sum2 - v.y * v.y) * dv.y - v.z * v.y * dv.z) * inv;
+  o.z = (-v.x * v.z * dv.x - v.y * v.z * dv.y + (sum2 - v.z * v.z) * dv.z) * inv;
+  return o;
+}
+
+// SH backward: writes dL/dsh, returns dL/dmean through the view direction.
+__device__ __forceinline__ float3 sh_backward(int deg, float3 pos, float3 campos, const float *__restrict__ sh,
+                                              const uint8_t *__restrict__ clamped, float3 gcol,
+                                              float *__restrict__ dL_dsh) {
+  const float3 dorig = make_float3(pos.x - campos.x, pos.y - campos.y, pos.z - campos.z);
+  const float len = sqrtf(dorig.x * dorig.x + dorig.y * dorig.y + dorig.z * dorig.z);
+  const float x = dorig.x / len, y = dorig.y / len, z = dorig.z / len;
+  const float g[3] = {gcol.x * (clamped[0] ? 0.f : 1.f), gcol.y * (clamped[1] ? 0.f : 1.f), gcol.z * (clamped[2] ? 0.f : 1.f)};
+  float dx[3] = {0.f, 0.f, 0.f}, dy[3] = {0.f, 0.f, 0.f}, dz[3] = {0.f, 0.f, 0.f};
+#define SH(k, ch) sh[(k) * 3 + (ch)]
+#define OUT(k, w)                                             \
+  {                                                           \
+    const float _w = (w);                                     \
+    dL_dsh[(k) * 3 + 0] = _w * g[0];                          \
+    dL_dsh[(k) * 3 + 1] = _w * g[1];                          \
+    dL_dsh[(k) * 3 + 2] = _w * g[2];                          \
+  }
+  OUT(0, bSH_C0)
+  if (deg > 0) {
+    OUT(1, -bSH_C1 * y) OUT(2, bSH_C1 * z) OUT(3, -bSH_C1 * x)
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+      dx[ch] = -bSH_C1 * SH(3, ch);
+      dy[ch] = -bSH_C1 * SH(1, ch);
+      dz[ch] = bSH_C1 * SH(2, ch);
+    }
+    if (deg > 1) {
+      const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+      OUT(4, bSH_C2[0] * xy) OUT(5, bSH_C2[1] * yz) OUT(6, bSH_C2[2] * (2.f * zz - xx - yy))
+      OUT(7, bSH_C2[3] * xz) OUT(8, bSH_C2[4] * (xx - yy))
+#pragma unroll
+      for (int ch = 0; ch < 3; ch++) {
+        dx[ch] += bSH_C2[0] * y * SH(4, ch) + bSH_C2[2] * 2.f * -x * SH(6, ch) + bSH_C2[3] * z * SH(7, ch) + bSH_C2[4] * 2.f * x * SH(8, ch);
+        dy[ch] += bSH_C2[0] * x * SH(4, ch) + bSH_C2[1] * z * SH(5, ch) + bSH_C2[2] * 2.f * -y * SH(6, ch) + bSH_C2[4] * 2.f * -y * SH(8, ch);
+        dz[ch] += bSH_C2[1] * y * SH(5, ch) + bSH_C2[2] * 2.f * 2.f * z * SH(6, ch) + bSH_C2[3] * x * SH(7, ch);
+      }
+      if (deg > 2) {
+        OUT(9, bSH_C3[0] * y * (3.f * xx - yy)) OUT(10, bSH_C3[1] * xy * z) OUT(11, bSH_C3[2] * y * (4.f * zz - xx - yy))
+        OUT(12, bSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)) OUT(13, bSH_C3[4] * x * (4.f * zz - xx - yy))
+        OUT(14, bSH_C3[5] * z * (xx - yy)) OUT(15, bSH_C3[6] * x * (xx - 3.f * yy))
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+          dx[ch] += (bSH_C3[0] * SH(9, ch) * 3.f * 2.f * xy + bSH_C3[1] * SH(10, ch) * yz + bSH_C3[2] * SH(11, ch) * -2.f * xy +
+                     bSH_C3[3] * SH(12, ch) * -3.f * 2.f * xz + bSH_C3[4] * SH(13, ch) * (-3.f * xx + 4.f * zz - yy) +
+                     bSH_C3[5] * SH(14, ch) * 2.f * xz + bSH_C3[6] * SH(15, ch) * 3.f * (xx - yy));
+          dy[ch] += (bSH_C3[0] * SH(9, ch) * 3.f * (xx - yy) + bSH_C3[1] * SH(10, ch) * xz +
+                     bSH_C3[2] * SH(11, ch) * (-3.f * yy + 4.f * zz - xx) + bSH_C3[3] * SH(12, ch) * -3.f * 2.f * yz +
+                     bSH_C3[4] * SH(13, ch) * -2.f * xy + bSH_C3[5] * SH(14, ch) * -2.f * yz + bSH_C3[6] * SH(15, ch) * -3.f * 2.f * xy);
+          dz[ch] += (bSH_C3[1] * SH(10, ch) * xy + bSH_C3[2] * SH(11, ch) * 4.f * 2.f * yz +
+                     bSH_C3[3] * SH(12, ch) * 3.f * (2.f * zz - xx - yy) + bSH_C3[4] * SH(13, ch) * 4.f * 2.f * xz +
+                     bSH_C3[5] * SH(14, ch) * (xx - yy));
+        }
+      }
+    }
+  }
+#undef SH
+#undef OUT
+  const float3 ddir = make_float3(dx[0] * g[0] + dx[1] * g[1] + dx[2] * g[2], dy[0] * g[0] + dy[1] * g[1] + dy[2] * g[2],
+                                  dz[0] * g[0] + dz[1] * g[1] + dz[2] * g[2]);
+  return dnormvdv(dorig, ddir);
+}
+
+__global__ __launch_bounds__(PRE_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g, const uint32_t *__restrict__ inv_pos,
+                                                            const float4 *__restrict__ inst_grad) {
+  __shared__ float wsum[PRE_BLOCK / 64][6];
+  const int tid = threadIdx.x;
+  const int idx = blockIdx.x * PRE_BLOCK + tid;
+  float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int radius = idx < p.P ? p.radii[idx] : 0;
+  if (radius > 0) {
+    // ---- 1. gather this Gaussian's instance partials (fixed order) ----
+    const uint32_t cnt = g.tiles_touched[idx];
+    const uint32_t first = g.point_offsets[idx] - cnt;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0;
+    for (uint32_t u = 0; u < cnt; u++) {
+      const uint32_t k = inv_pos[first + u];
+      const float4 *src = inst_grad + (size_t)k * REC_F4;
+      const float4 a0 = src[0], a1 = src[1], a2 = src[2];
+      s0.x += a0.x; s0.y += a0.y; s0.z += a0.z; s0.w += a0.w;
+      s1.x += a1.x; s1.y += a1.y; s1.z += a1.z; s1.w += a1.w;
+      s2.x += a2.x; s2.y += a2.y;
+    }
+    const float g2x = s0.x, g2y = s0.y;           // dL/dmean2D (NDC-scaled)
+    const float gcx = s0.z, gcy = s0.w, gcz = s1.x;  // dL/dconic a, b, c
+    const float gop = s1.y;
+    const float3 gcol = make_float3(s1.z, s1.w, s2.x);
+    const float gz = s2.y;
+    p.dL_dmean2D[3 * (size_t)idx] = g2x; p.dL_dmean2D[3 * (size_t)idx + 1] = g2y;
+    p.dL_dconic[4 * (size_t)idx] = gcx; p.dL_dconic[4 * (size_t)idx + 1] = gcy; p.dL_dconic[4 * (size_t)idx + 3] = gcz;
+    p.dL_dopacity[idx] = gop;
+    p.dL_dcolor[3 * (size_t)idx] = gcol.x; p.dL_dcolor[3 * (size_t)idx + 1] = gcol.y; p.dL_dcolor[3 * (size_t)idx + 2] = gcol.z;
+    p.dL_ddepth[idx] = gz;
+
+    // ---- 2. conic -> cov2D -> cov3D, M = J Rcw, t ----
+    const float3 mean = make_float3(p.means3D[3 * (size_t)idx], p.means3D[3 * (size_t)idx + 1], p.means3D[3 * (size_t)idx + 2]);
+    const float *vm = p.viewmatrix;
+    const float *c6 = p.cov3Ds + 6 * (size_t)idx;
+    const float fx = p.focal_x, fy = p.focal_y;
+    float3 t = xform4x3(vm, mean);
+    const float3 pC = t;  // un-clamped camera-space point
+    const float limx = 1.3f * p.tanfovx, limy = 1.3f * p.tanfovy;
+    const float txtz = t.x / t.z, tytz = t.y / t.z;
+    t.x = fminf(limx, fmaxf(-limx, txtz)) * t.z;
+    t.y = fminf(limy, fmaxf(-limy, tytz)) * t.z;
+    const float xmul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+    const float ymul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+    const float J00 = fx / t.z, J02 = -(fx * t.x) / (t.z * t.z);
+    const float J11 = fy / t.z, J12 = -(fy * t.y) / (t.z * t.z);
+    float Rc[3][3], M[2][3];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = 0; c < 3; c++) Rc[r][c] = vm[4 * c + r];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      M[0][k] = Rc[0][k] * J00 + Rc[2][k] * J02;
+      M[1][k] = Rc[1][k] * J11 + Rc[2][k] * J12;
+    }
+    const float V[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+    float MV[2][3];
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) MV[r][k] = M[r][0] * V[k][0] + M[r][1] * V[k][1] + M[r][2] * V[k][2];
+    const float a = (MV[0][0] * M[0][0] + MV[0][1] * M[0][1] + MV[0][2] * M[0][2]) + 0.3f;
+    const float b = MV[1][0] * M[0][0] + MV[1][1] * M[0][1] + MV[1][2] * M[0][2];
+    const float c = (MV[1][0] * M[1][0] + MV[1][1] * M[1][1] + MV[1][2] * M[1][2]) + 0.3f;
+    const float denom = a * c - b * b;
+    float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+    const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+    float gcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (denom2inv != 0.f) {
+      dL_da = denom2inv * (-c * c * gcx + 2 * b * c * gcy + (denom - a * c) * gcz);
+      dL_dc = denom2inv * (-a * a * gcz + 2 * a * b * gcy + (denom - a * c) * gcx);
+      dL_db = denom2inv * 2 * (b * c * gcx - (denom + 2 * b * b) * gcy + a * b * gcz);
+      gcov[0] = (M[0][0] * M[0][0] * dL_da + M[0][0] * M[1][0] * dL_db + M[1][0] * M[1][0] * dL_dc);
+      gcov[3] = (M[0][1] * M[0][1] * dL_da + M[0][1] * M[1][1] * dL_db + M[1][1] * M[1][1] * dL_dc);
+      gcov[5] = (M[0][2] * M[0][2] * dL_da + M[0][2] * M[1][2] * dL_db + M[1][2] * M[1][2] * dL_dc);
+      gcov[1] = 2 * M[0][0] * M[0][1] * dL_da + (M[0][0] * M[1][1] + M[0][1] * M[1][0]) * dL_db + 2 * M[1][0] * M[1][1] * dL_dc;
+      gcov[2] = 2 * M[0][0] * M[0][2] * dL_da + (M[0][0] * M[1][2] + M[0][2] * M[1][0]) * dL_db + 2 * M[1][0] * M[1][2] * dL_dc;
+      gcov[4] = 2 * M[0][2] * M[0][1] * dL_da + (M[0][1] * M[1][2] + M[0][2] * M[1][1]) * dL_db + 2 * M[1][1] * M[1][2] * dL_dc;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) p.dL_dcov3D[6 * (size_t)idx + k] = gcov[k];
+    float dM[2][3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      dM[0][k] = 2 * MV[0][k] * dL_da + MV[1][k] * dL_db;
+      dM[1][k] = 2 * MV[1][k] * dL_dc + MV[0][k] * dL_db;
+    }
+    const float dJ00 = Rc[0][0] * dM[0][0] + Rc[0][1] * dM[0][1] + Rc[0][2] * dM[0][2];
+    const float dJ02 = Rc[2][0] * dM[0][0] + Rc[2][1] * dM[0][1] + Rc[2][2] * dM[0][2];
+    const float dJ11 = Rc[1][0] * dM[1][0] + Rc[1][1] * dM[1][1] + Rc[1][2] * dM[1][2];
+    const float dJ12 = Rc[2][0] * dM[1][0] + Rc[2][1] * dM[1][1] + Rc[2][2] * dM[1][2];
+    const float tz = 1.f / t.z, tz2 = tz * tz, tz3 = tz2 * tz;
+    float3 gt;
+    gt.x = xmul * -fx * tz2 * dJ02;
+    gt.y = ymul * -fy * tz2 * dJ12;
+    gt.z = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2 * fx * t.x) * tz3 * dJ02 + (2 * fy * t.y) * tz3 * dJ12;
+    // tau: rho += g, theta += t x g (clamped t) + sum_k col_k(Rcw) x dL/dcol_k(Rcw)
+    const float3 txg = cross3(t, gt);
+    tau[0] += gt.x; tau[1] += gt.y; tau[2] += gt.z;
+    tau[3] += txg.x; tau[4] += txg.y; tau[5] += txg.z;
+    float3 gm = make_float3(Rc[0][0] * gt.x + Rc[1][0] * gt.y + Rc[2][0] * gt.z,
+                            Rc[0][1] * gt.x + Rc[1][1] * gt.y + Rc[2][1] * gt.z,
+                            Rc[0][2] * gt.x + Rc[1][2] * gt.y + Rc[2][2] * gt.z);
+    {
+      float3 th = make_float3(0.f, 0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const float3 ck = make_float3(Rc[0][k], Rc[1][k], Rc[2][k]);
+        const float3 gk = make_float3(J00 * dM[0][k], J11 * dM[1][k], J02 * dM[0][k] + J12 * dM[1][k]);
+        const float3 cr = cross3(ck, gk);
+        th.x += cr.x; th.y += cr.y; th.z += cr.z;
+      }
+      tau[3] += th.x; tau[4] += th.y; tau[5] += th.z;
+    }
+
+    // ---- 3. mean2D -> mean3D, tau ----
+    const float *pj = p.projmatrix;
+    const float4 mh = xform4x4(pj, mean);
+    const float mw = 1.0f / (mh.w + 0.0000001f);
+    const float mul1 = (pj[0] * mean.x + pj[4] * mean.y + pj[8] * mean.z + pj[12]) * mw * mw;
+    const float mul2 = (pj[1] * mean.x + pj[5] * mean.y + pj[9] * mean.z + pj[13]) * mw * mw;
+    gm.x += (pj[0] * mw - pj[3] * mul1) * g2x + (pj[1] * mw - pj[3] * mul2) * g2y;
+    gm.y += (pj[4] * mw - pj[7] * mul1) * g2x + (pj[5] * mw - pj[7] * mul2) * g2y;
+    gm.z += (pj[8] * mw - pj[11] * mul1) * g2x + (pj[9] * mw - pj[11] * mul2) * g2y;
+    {
+      const float alpha_ = 1.0f * mw, beta_ = -mh.x * mw * mw, gamma_ = -mh.y * mw * mw;
+      const float pa = p.projmatrix_raw[0], pb = p.projmatrix_raw[5], pe = p.projmatrix_raw[11];
+      const float3 d1 = make_float3(alpha_ * pa, 0.f, beta_ * pe), d2 = make_float3(0.f, alpha_ * pb, gamma_ * pe);
+      const float3 c1 = cross3(pC, d1), c2 = cross3(pC, d2);
+      tau[0] += g2x * d1.x + g2y * d2.x; tau[1] += g2x * d1.y + g2y * d2.y; tau[2] += g2x * d1.z + g2y * d2.z;
+      tau[3] += g2x * c1.x + g2y * c2.x; tau[4] += g2x * c1.y + g2y * c2.y; tau[5] += g2x * c1.z + g2y * c2.z;
+    }
+    // ---- 4. depth -> mean3D, tau: dz/dtau = [0,0,1, y, -x, 0] ----
+    gm.x += gz * vm[2]; gm.y += gz * vm[6]; gm.z += gz * vm[10];
+    tau[2] += gz;
+    tau[3] += gz * pC.y;
+    tau[4] += gz * -pC.x;
+    // ---- 5. colour -> SH, view direction -> mean3D, tau ----
+    if (p.shs) {
+      const float3 cam = make_float3(p.campos[0], p.campos[1], p.campos[2]);
+      const float3 dmean = sh_backward(p.D, mean, cam, p.shs + (size_t)idx * p.M * 3, g.clamped + 3 * (size_t)idx, gcol,
+                                       p.dL_dsh + (size_t)idx * p.M * 3);
+      gm.x += dmean.x; gm.y += dmean.y; gm.z += dmean.z;
+      tau[0] -= dmean.x; tau[1] -= dmean.y; tau[2] -= dmean.z;
+    }
+    p.dL_dmean3D[3 * (size_t)idx] = gm.x; p.dL_dmean3D[3 * (size_t)idx + 1] = gm.y; p.dL_dmean3D[3 * (size_t)idx + 2] = gm.z;
+    // ---- 6. cov3D -> scale, rotation ----
+    if (p.scales) {
+      const float3 sc = make_float3(p.scales[3 * (size_t)idx], p.scales[3 * (size_t)idx + 1], p.scales[3 * (size_t)idx + 2]);
+      const float4 q = reinterpret_cast<const float4 *>(p.rotations)[idx];
+      const float r = q.x, x = q.y, y = q.z, z = q.w;
+      const float R[3][3] = {{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
+                             {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
+                             {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}};
+      const float s[3] = {p.scale_modifier * sc.x, p.scale_modifier * sc.y, p.scale_modifier * sc.z};
+      const float dS[3][3] = {{gcov[0], 0.5f * gcov[1], 0.5f * gcov[2]},
+                              {0.5f * gcov[1], gcov[3], 0.5f * gcov[4]},
+                              {0.5f * gcov[2], 0.5f * gcov[4], gcov[5]}};
+      float dA[3][3];  // A = S R^T, dL/dA = 2 A dSigma
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++)
+          dA[i][cc] = 2.0f * ((s[i] * R[0][i]) * dS[0][cc] + (s[i] * R[1][i]) * dS[1][cc] + (s[i] * R[2][i]) * dS[2][cc]);
+#pragma unroll
+      for (int k = 0; k < 3; k++) p.dL_dscale[3 * (size_t)idx + k] = R[0][k] * dA[k][0] + R[1][k] * dA[k][1] + R[2][k] * dA[k][2];
+      float gR[3][3];  // dL/dR[j][i] = s_i dA[i][j]
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) gR[j][i] = s[i] * dA[i][j];
+      float4 dq;
+      dq.x = 2 * z * (gR[1][0] - gR[0][1]) + 2 * y * (gR[0][2] - gR[2][0]) + 2 * x * (gR[2][1] - gR[1][2]);
+      dq.y = 2 * y * (gR[0][1] + gR[1][0]) + 2 * z * (gR[0][2] + gR[2][0]) + 2 * r * (gR[2][1] - gR[1][2]) - 4 * x * (gR[2][2] + gR[1][1]);
+      dq.z = 2 * x * (gR[0][1] + gR[1][0]) + 2 * r * (gR[0][2] - gR[2][0]) + 2 * z * (gR[2][1] + gR[1][2]) - 4 * y * (gR[2][2] + gR[0][0]);
+      dq.w = 2 * r * (gR[1][0] - gR[0][1]) + 2 * x * (gR[0][2] + gR[2][0]) + 2 * y * (gR[2][1] + gR[1][2]) - 4 * z * (gR[1][1] + gR[0][0]);
+      reinterpret_cast<float4 *>(p.dL_drot)[idx] = dq;
+    }
+    if (p.dL_dtau) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) p.dL_dtau[6 * (size_t)idx + k] = tau[k];
+    }
+  }
+  // ---- 7. workgroup partial of dL/dtau (fixed reduction tree) ----
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    float v = tau[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((tid & 63) == 0) wsum[tid >> 6][k] = v;
+  }
+  __syncthreads();
+  if (tid < 6) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < PRE_BLOCK / 64; w++) v += wsum[w][tid];
+    g.tau_partials[(size_t)blockIdx.x * 8 + tid] = v;
+  }
+}
+
+// Final fixed-order sum of the workgroup partials -> dL_dtau_sum[6] (fp64 accumulation).
+__global__ __launch_bounds__(256) void k_tau_finalize(int nblk, const float *__restrict__ partials, float *__restrict__ out) {
+  __shared__ double sh[256];
+  const int tid = threadIdx.x;
+  for (int k = 0; k < 6; k++) {
+    double v = 0.0;
+    for (int i = tid; i < nblk; i += 256) v += (double)partials[(size_t)i * 8 + k];
+    sh[tid] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) sh[tid] += sh[tid + o];
+      __syncthreads();
+    }
+    if (tid == 0) out[k] = (float)sh[0];
+    __syncthreads();
+  }
+}
+
+int launch_gaussian_backward(const BwdParams &p, const GeomWS &g, const BinWS &b, hipStream_t s) {
+  const int nblk = (p.P + PRE_BLOCK - 1) / PRE_BLOCK;
+  {
+    GsajProfScope ps(ST_GAUSSIAN_BWD, s);
+    hipLaunchKernelGGL(k_gaussian_bwd, dim3(nblk), dim3(PRE_BLOCK), 0, s, p, g, b.inv_pos, b.inst_grad);
+  }
+  if (p.dL_dtau_sum) {
+    GsajProfScope ps(ST_TAU_FINALIZE, s);
+    hipLaunchKernelGGL(k_tau_finalize, dim3(1), dim3(256), 0, s, nblk, g.tau_partials, p.dL_dtau_sum);
+  }
+  GSAJ_HIP_CHECK(hipGetLastError());
+  return GSAJ_OK;
+}

@@ -1,0 +1,190 @@
+// gsaj_common.h -- shared host/device declarations of libgsaj_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/gsaj.h"
+
+#define GSAJ_WAVE 64
+#define TILE GSAJ_TILE
+#define TILE_PIXELS (TILE * TILE)
+#define PRE_BLOCK 256   // Gaussians per workgroup in the per-Gaussian kernels
+#define REC_F4 3        // float4s per sorted-instance record
+#define IGRAD_F 12      // floats per per-instance gradient slot (10 used, padded to 3 x float4)
+
+// ---- per-instance record (one per (tile, Gaussian) pair, in sorted order) ---------------
+//   r0 = (mean2D.x, mean2D.y, depth, gaussian id as bits)
+//   r1 = (conic.a, conic.b, conic.c, opacity)
+//   r2 = (colour.r, colour.g, colour.b, unused)
+// Written once after the sort so that the compositors stream contiguous 48-B records
+// instead of gathering four arrays through an index (forward.cu:491-498 / backward.cu:742-752).
+
+// ---- workspace layouts ------------------------------------------------------------------
+static inline __host__ __device__ size_t gsaj_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct GeomWS {  // per-Gaussian state (reference: GeometryState, rasterizer_impl.h:29-44)
+  float *depths;          // [P]
+  float2 *means2D;        // [P]
+  float *cov3D;           // [P*6]
+  float4 *conic_opacity;  // [P]
+  float *rgb;             // [P*3]
+  uint8_t *clamped;       // [P*3]
+  uint32_t *tiles_touched;  // [P]
+  uint32_t *point_offsets;  // [P] inclusive scan of tiles_touched
+  int *internal_radii;      // [P]
+  uint32_t *block_sums;     // [nblk] per-workgroup totals, then exclusive offsets
+  uint32_t *counters;       // [0] num_rendered, [1] error flag
+  float *tau_partials;      // [nblk*8] per-workgroup dL/dtau partial sums
+};
+
+static inline __host__ __device__ size_t geom_carve(char *base, size_t P, GeomWS *g) {
+  size_t off = 0;
+  size_t nblk = (P + PRE_BLOCK - 1) / PRE_BLOCK;
+  if (nblk == 0) nblk = 1;
+#define CARVE(field, type, count)                                \
+  do {                                                           \
+    if (g) g->field = reinterpret_cast<type *>(base + off);      \
+    off += gsaj_align(sizeof(type) * (size_t)(count));           \
+  } while (0)
+  CARVE(depths, float, P);
+  CARVE(means2D, float2, P);
+  CARVE(cov3D, float, P * 6);
+  CARVE(conic_opacity, float4, P);
+  CARVE(rgb, float, P * 3);
+  CARVE(clamped, uint8_t, P * 3);
+  CARVE(tiles_touched, uint32_t, P);
+  CARVE(point_offsets, uint32_t, P);
+  CARVE(internal_radii, int, P);
+  CARVE(block_sums, uint32_t, nblk);
+  CARVE(counters, uint32_t, 64);
+  CARVE(tau_partials, float, nblk * 8);
+  return off;
+}
+
+struct ImageWS {  // reference: ImageState, rasterizer_impl.h:46-53
+  float *final_T;       // [H*W]
+  uint32_t *n_contrib;  // [H*W]
+  uint2 *ranges;        // [tiles]
+};
+
+static inline __host__ __device__ size_t image_carve(char *base, int W, int H, ImageWS *s) {
+  size_t off = 0;
+  size_t N = (size_t)W * H;
+  size_t tiles = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+  ImageWS *g = s;
+  CARVE(final_T, float, N);
+  CARVE(n_contrib, uint32_t, N);
+  CARVE(ranges, uint2, tiles);
+  return off;
+}
+
+struct BinWS {  // reference: BinningState, rasterizer_impl.h:55-66
+  uint64_t *keys_unsorted;  // [R]
+  uint64_t *keys;           // [R]
+  uint32_t *vals_unsorted;  // [R]
+  uint32_t *point_list;     // [R] sorted Gaussian ids
+  uint32_t *inv_pos;        // [R] emission slot -> sorted position
+  float4 *records;          // [R*3]
+  float4 *inst_grad;        // [R*3] per-instance partial gradients (backward)
+  char *sort_temp;
+  size_t sort_temp_bytes;
+};
+
+size_t gsaj_sort_temp_bytes(int R);  // binning.hip
+
+static inline size_t bin_carve(char *base, size_t R, size_t sort_temp_bytes, BinWS *g) {
+  size_t off = 0;
+  size_t Rn = R ? R : 1;
+  CARVE(keys_unsorted, uint64_t, Rn);
+  CARVE(keys, uint64_t, Rn);
+  CARVE(vals_unsorted, uint32_t, Rn);
+  CARVE(point_list, uint32_t, Rn);
+  CARVE(inv_pos, uint32_t, Rn);
+  CARVE(records, float4, Rn * REC_F4);
+  CARVE(inst_grad, float4, Rn * REC_F4);
+  CARVE(sort_temp, char, sort_temp_bytes);
+  if (g) g->sort_temp_bytes = sort_temp_bytes;
+  return off;
+}
+#undef CARVE
+
+// ---- error plumbing (api.hip) -------------------------------------------------------------
+void gsaj_set_error(const char *fmt, ...);
+#define GSAJ_HIP_CHECK(expr)                                                          \
+  do {                                                                                \
+    hipError_t _e = (expr);                                                           \
+    if (_e != hipSuccess) {                                                           \
+      gsaj_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return GSAJ_ERR_HIP;                                                            \
+    }                                                                                 \
+  } while (0)
+
+// ---- optional per-stage timing with HIP events on the launch stream (api.hip) --------------
+enum GsajStage {
+  ST_PREPROCESS = 0, ST_SCAN, ST_EMIT_KEYS, ST_SORT, ST_RANGES_RECORDS, ST_RENDER_FWD, ST_RENDER_BWD, ST_GAUSSIAN_BWD,
+  ST_TAU_FINALIZE, ST_DENSE_BWD, ST_DENSE_REDUCE, ST_COUNT
+};
+void gsaj_prof_mark(int stage, int is_stop, hipStream_t s);
+struct GsajProfScope {
+  int stage;
+  hipStream_t s;
+  GsajProfScope(int st, hipStream_t stream) : stage(st), s(stream) { gsaj_prof_mark(stage, 0, s); }
+  ~GsajProfScope() { gsaj_prof_mark(stage, 1, s); }
+};
+
+// ---- launchers implemented in the .hip files -----------------------------------------------
+struct FwdParams {
+  int P, D, M, W, H;
+  const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
+  const float *viewmatrix, *projmatrix, *campos;
+  float scale_modifier, tanfovx, tanfovy, focal_x, focal_y;
+  int prefiltered;
+  int grid_x, grid_y;
+};
+
+int launch_preprocess(const FwdParams &p, int *radii, const GeomWS &g, hipStream_t s);
+int launch_emit_keys(int P, int grid_x, int grid_y, const int *radii, const GeomWS &g, const BinWS &b, hipStream_t s);
+int launch_sort(int R, int end_bit, const BinWS &b, hipStream_t s);
+int launch_ranges_and_records(int P, int R, int grid_x, int grid_y, const int *radii, const float *features,
+                              const GeomWS &g, const BinWS &b, const ImageWS &im, hipStream_t s);
+int launch_render_forward(int W, int H, int grid_x, int grid_y, const float *bg, const BinWS &b, const ImageWS &im,
+                          float *out_color, float *out_depth, float *out_opacity, int *n_touched, hipStream_t s);
+int launch_render_backward(int R, int W, int H, int grid_x, int grid_y, const float *bg, const BinWS &b,
+                           const ImageWS &im, const float *dL_dpix, const float *dL_dpix_depth, hipStream_t s);
+struct BwdParams {
+  int P, D, M, W, H;
+  const float *means3D, *shs, *scales, *rotations, *cov3Ds;
+  const float *viewmatrix, *projmatrix, *projmatrix_raw, *campos;
+  float scale_modifier, tanfovx, tanfovy, focal_x, focal_y;
+  int grid_x, grid_y;
+  const int *radii;
+  float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_ddepth, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale,
+      *dL_drot, *dL_dtau, *dL_dtau_sum;
+};
+int launch_gaussian_backward(const BwdParams &p, const GeomWS &g, const BinWS &b, hipStream_t s);
+int launch_mark_visible(int P, const float *means3D, const float *viewmatrix, uint8_t *present, hipStream_t s);
+
+// ---- small device helpers -------------------------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ float3 xform4x3(const float *m, float3 p) {
+  return make_float3(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12], m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+                     m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14]);
+}
+__device__ __forceinline__ float4 xform4x4(const float *m, float3 p) {
+  return make_float4(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12], m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+                     m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14], m[3] * p.x + m[7] * p.y + m[11] * p.z + m[15]);
+}
+// pixel = ((ndc + 1) * S - 1) / 2 in double, as the reference's un-suffixed literals do (auxiliary.h:41-44)
+__device__ __forceinline__ float ndc2pix(float v, int S) { return (float)((((double)v + 1.0) * (double)S - 1.0) * 0.5); }
+
+__device__ __forceinline__ void tile_rect(float px, float py, int r, int gx, int gy, int &x0, int &y0, int &x1, int &y1) {
+  x0 = min(gx, max(0, (int)((px - (float)r) / (float)TILE)));
+  y0 = min(gy, max(0, (int)((py - (float)r) / (float)TILE)));
+  x1 = min(gx, max(0, (int)((px + (float)r + (float)(TILE - 1)) / (float)TILE)));
+  y1 = min(gy, max(0, (int)((py + (float)r + (float)(TILE - 1)) / (float)TILE)));
+}
+__device__ __forceinline__ float3 cross3(float3 a, float3 b) {
+  return make_float3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+#endif

@@ -1,0 +1,281 @@
+// preprocess.hip -- per-Gaussian forward stage and instance-key emission (gfx950).
+//
+// One lane per Gaussian, SoA streaming loads/stores (HBM-bound stage, SURVEY 8d regime 1).
+// The workgroup also produces the block-local inclusive scan of tiles_touched, so the
+// prefix sum over all Gaussians costs no extra pass over P (the reference runs a separate
+// cub::DeviceScan over tiles_touched, rasterizer_impl.cu:327).
+//
+// Compiled with -ffp-contract=off: radius and tile rectangle are integers derived from
+// fp32 arithmetic, and must not depend on FMA contraction.
+//
+// Behaviour follows forward.cu:157-401 (preprocessCUDA), :76-115 (computeCov2D),
+// :120-154 (computeCov3D), :22-73 (computeColorFromSH), auxiliary.h:139-164 (in_frustum),
+// rasterizer_impl.cu:70-111 (duplicateWithKeys), :54-66 (checkFrustum).
+#include "gsaj_common.h"
+
+__constant__ float kSH_C0 = 0.28209479177387814f;
+__constant__ float kSH_C1 = 0.4886025119029199f;
+__constant__ float kSH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f,
+                                0.5462742152960396f};
+__constant__ float kSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                                -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+
+__device__ __forceinline__ float3 ld3(const float *p, size_t i) { return make_float3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
+
+// Sigma = R S^2 R^T (upper triangle) from scale and an un-normalised quaternion (r,x,y,z).
+__device__ __forceinline__ void cov3d_from_scale_rot(float3 sc, float mod, float4 q, float *c6) {
+  const float r = q.x, x = q.y, y = q.z, z = q.w;
+  float R[3][3] = {{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
+                   {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
+                   {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}};
+  const float s[3] = {mod * sc.x, mod * sc.y, mod * sc.z};
+  float A[3][3];  // A = S R^T
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) A[i][j] = s[i] * R[j][i];
+  float S[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+#pragma unroll
+    for (int b = a; b < 3; b++) S[a][b] = A[0][a] * A[0][b] + A[1][a] * A[1][b] + A[2][a] * A[2][b];
+  c6[0] = S[0][0]; c6[1] = S[0][1]; c6[2] = S[0][2]; c6[3] = S[1][1]; c6[4] = S[1][2]; c6[5] = S[2][2];
+}
+
+// Dilated EWA covariance (a,b,c) of the projected Gaussian.
+__device__ __forceinline__ float3 cov2d_forward(float3 mean, float fx, float fy, float tanx, float tany, const float *c6,
+                                                const float *vm) {
+  float3 t = xform4x3(vm, mean);
+  const float limx = 1.3f * tanx, limy = 1.3f * tany;
+  const float txtz = t.x / t.z, tytz = t.y / t.z;
+  t.x = fminf(limx, fmaxf(-limx, txtz)) * t.z;
+  t.y = fminf(limy, fmaxf(-limy, tytz)) * t.z;
+  const float J00 = fx / t.z, J02 = -(fx * t.x) / (t.z * t.z);
+  const float J11 = fy / t.z, J12 = -(fy * t.y) / (t.z * t.z);
+  float M[2][3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {  // M = J * Rcw, Rcw[r][k] = vm[4k + r]
+    M[0][k] = vm[4 * k + 0] * J00 + vm[4 * k + 1] * 0.0f + vm[4 * k + 2] * J02;
+    M[1][k] = vm[4 * k + 0] * 0.0f + vm[4 * k + 1] * J11 + vm[4 * k + 2] * J12;
+  }
+  const float V[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+  float X[2][3];
+#pragma unroll
+  for (int r = 0; r < 2; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) X[r][c] = M[r][0] * V[c][0] + M[r][1] * V[c][1] + M[r][2] * V[c][2];
+  float3 cov;
+  cov.x = (X[0][0] * M[0][0] + X[0][1] * M[0][1] + X[0][2] * M[0][2]) + 0.3f;
+  cov.y = X[1][0] * M[0][0] + X[1][1] * M[0][1] + X[1][2] * M[0][2];
+  cov.z = (X[1][0] * M[1][0] + X[1][1] * M[1][1] + X[1][2] * M[1][2]) + 0.3f;
+  return cov;
+}
+
+__device__ __forceinline__ float3 sh_to_rgb(int deg, float3 pos, float3 campos, const float *sh, uint8_t *clamped) {
+  float3 d = make_float3(pos.x - campos.x, pos.y - campos.y, pos.z - campos.z);
+  const float len = sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
+  const float x = d.x / len, y = d.y / len, z = d.z / len;
+  float out[3];
+#pragma unroll
+  for (int ch = 0; ch < 3; ch++) {
+#define SHC(k) sh[(k) * 3 + ch]
+    float res = kSH_C0 * SHC(0);
+    if (deg > 0) {
+      res = res - kSH_C1 * y * SHC(1) + kSH_C1 * z * SHC(2) - kSH_C1 * x * SHC(3);
+      if (deg > 1) {
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        res = res + kSH_C2[0] * xy * SHC(4) + kSH_C2[1] * yz * SHC(5) + kSH_C2[2] * (2.0f * zz - xx - yy) * SHC(6) +
+              kSH_C2[3] * xz * SHC(7) + kSH_C2[4] * (xx - yy) * SHC(8);
+        if (deg > 2) {
+          res = res + kSH_C3[0] * y * (3.0f * xx - yy) * SHC(9) + kSH_C3[1] * xy * z * SHC(10) +
+                kSH_C3[2] * y * (4.0f * zz - xx - yy) * SHC(11) + kSH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * SHC(12) +
+                kSH_C3[4] * x * (4.0f * zz - xx - yy) * SHC(13) + kSH_C3[5] * z * (xx - yy) * SHC(14) +
+                kSH_C3[6] * x * (xx - 3.0f * yy) * SHC(15);
+        }
+      }
+    }
+#undef SHC
+    res += 0.5f;
+    clamped[ch] = (res < 0.0f);
+    out[ch] = res < 0.0f ? 0.0f : res;
+  }
+  return make_float3(out[0], out[1], out[2]);
+}
+
+__global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__restrict__ radii, GeomWS g) {
+  __shared__ uint32_t scan[PRE_BLOCK];
+  const int tid = threadIdx.x;
+  const int idx = blockIdx.x * PRE_BLOCK + tid;
+  uint32_t touched = 0;
+  if (idx < p.P) {
+    int my_radius_i = 0;
+    float2 xy = make_float2(0.f, 0.f);
+    float depth = 0.f;
+    float4 con_o = make_float4(0.f, 0.f, 0.f, 0.f);
+    float3 rgb = make_float3(0.f, 0.f, 0.f);
+    uint8_t cl[3] = {0, 0, 0};
+    float c6s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float3 p_orig = ld3(p.means3D, idx);
+    const float3 p_view = xform4x3(p.viewmatrix, p_orig);
+    if (p_view.z <= 0.2f) {
+      if (p.prefiltered) g.counters[1] = 1u;  // the reference traps here (auxiliary.h:156-160)
+    } else {
+      const float4 p_hom = xform4x4(p.projmatrix, p_orig);
+      const float p_w = 1.0f / (p_hom.w + 0.0000001f);
+      const float3 p_proj = make_float3(p_hom.x * p_w, p_hom.y * p_w, p_hom.z * p_w);
+      const float *c6;
+      if (p.cov3D_precomp) {
+        c6 = p.cov3D_precomp + 6 * (size_t)idx;
+      } else {
+        const float3 sc = ld3(p.scales, idx);
+        const float4 q = reinterpret_cast<const float4 *>(p.rotations)[idx];
+        cov3d_from_scale_rot(sc, p.scale_modifier, q, c6s);
+        c6 = c6s;
+      }
+      const float3 cov = cov2d_forward(p_orig, p.focal_x, p.focal_y, p.tanfovx, p.tanfovy, c6, p.viewmatrix);
+      const float det = cov.x * cov.z - cov.y * cov.y;
+      if (det != 0.0f) {
+        const float det_inv = 1.f / det;
+        const float3 conic = make_float3(cov.z * det_inv, -cov.y * det_inv, cov.x * det_inv);
+        const float mid = 0.5f * (cov.x + cov.z);
+        const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
+        const float lambda1 = mid + sq, lambda2 = mid - sq;
+        const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+        const float2 pim = make_float2(ndc2pix(p_proj.x, p.W), ndc2pix(p_proj.y, p.H));
+        int x0, y0, x1, y1;
+        tile_rect(pim.x, pim.y, (int)my_radius, p.grid_x, p.grid_y, x0, y0, x1, y1);
+        const int area = (x1 - x0) * (y1 - y0);
+        if (area != 0) {
+          if (!p.colors_precomp) {
+            const float3 cam = make_float3(p.campos[0], p.campos[1], p.campos[2]);
+            rgb = sh_to_rgb(p.D, p_orig, cam, p.shs + (size_t)idx * p.M * 3, cl);
+          }
+          depth = p_view.z;
+          my_radius_i = (int)my_radius;
+          xy = pim;
+          con_o = make_float4(conic.x, conic.y, conic.z, p.opacities[idx]);
+          touched = (uint32_t)area;
+        }
+      }
+    }
+    radii[idx] = my_radius_i;
+    g.depths[idx] = depth;
+    g.means2D[idx] = xy;
+    g.conic_opacity[idx] = con_o;
+    if (!p.cov3D_precomp) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) g.cov3D[6 * (size_t)idx + k] = c6s[k];
+    }
+    if (!p.colors_precomp) {
+      g.rgb[3 * (size_t)idx] = rgb.x; g.rgb[3 * (size_t)idx + 1] = rgb.y; g.rgb[3 * (size_t)idx + 2] = rgb.z;
+      g.clamped[3 * (size_t)idx] = cl[0]; g.clamped[3 * (size_t)idx + 1] = cl[1]; g.clamped[3 * (size_t)idx + 2] = cl[2];
+    }
+    g.tiles_touched[idx] = touched;
+  }
+  // block-local inclusive scan of tiles_touched (Hillis-Steele over 256 lanes)
+  scan[tid] = touched;
+  __syncthreads();
+#pragma unroll
+  for (int o = 1; o < PRE_BLOCK; o <<= 1) {
+    uint32_t v = (tid >= o) ? scan[tid - o] : 0u;
+    __syncthreads();
+    scan[tid] += v;
+    __syncthreads();
+  }
+  if (idx < p.P) g.point_offsets[idx] = scan[tid];
+  if (tid == PRE_BLOCK - 1) g.block_sums[blockIdx.x] = scan[tid];
+}
+
+// Exclusive scan of the per-workgroup totals (one workgroup; nblk = P/256 is small) and the
+// grand total R -> counters[0].
+__global__ __launch_bounds__(1024) void k_scan_blocks(int nblk, uint32_t *__restrict__ block_sums,
+                                                      uint32_t *__restrict__ counters) {
+  __shared__ uint32_t sh[1024];
+  __shared__ uint32_t carry;
+  const int tid = threadIdx.x;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nblk; base += 1024) {
+    const int i = base + tid;
+    const uint32_t v = (i < nblk) ? block_sums[i] : 0u;
+    sh[tid] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      uint32_t a = (tid >= o) ? sh[tid - o] : 0u;
+      __syncthreads();
+      sh[tid] += a;
+      __syncthreads();
+    }
+    const uint32_t c = carry;
+    if (i < nblk) block_sums[i] = c + sh[tid] - v;  // exclusive
+    __syncthreads();
+    if (tid == 1023) carry = c + sh[1023];
+    __syncthreads();
+  }
+  if (tid == 0) counters[0] = carry;
+}
+
+// One (tile, depth) key + Gaussian id per touched tile, written at the Gaussian's slot range.
+// Also turns point_offsets into the global inclusive scan.
+__global__ __launch_bounds__(PRE_BLOCK) void k_emit_keys(int P, int gx, int gy, const int *__restrict__ radii, GeomWS g,
+                                                         uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+  const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
+  if (idx >= P) return;
+  const uint32_t incl = g.block_sums[blockIdx.x] + g.point_offsets[idx];
+  g.point_offsets[idx] = incl;
+  const int r = radii[idx];
+  if (r > 0) {
+    uint32_t off = incl - g.tiles_touched[idx];
+    const float2 xy = g.means2D[idx];
+    int x0, y0, x1, y1;
+    tile_rect(xy.x, xy.y, r, gx, gy, x0, y0, x1, y1);
+    const uint32_t dbits = __float_as_uint(g.depths[idx]);
+    for (int y = y0; y < y1; y++)
+      for (int x = x0; x < x1; x++) {
+        keys[off] = ((uint64_t)(uint32_t)(y * gx + x) << 32) | dbits;
+        vals[off] = (uint32_t)idx;
+        off++;
+      }
+  }
+}
+
+__global__ __launch_bounds__(PRE_BLOCK) void k_mark_visible(int P, const float *__restrict__ means3D,
+                                                            const float *__restrict__ vm, uint8_t *__restrict__ present) {
+  const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
+  if (idx >= P) return;
+  const float3 pv = xform4x3(vm, ld3(means3D, idx));
+  present[idx] = pv.z > 0.2f;
+}
+
+int launch_preprocess(const FwdParams &p, int *radii, const GeomWS &g, hipStream_t s) {
+  const int nblk = (p.P + PRE_BLOCK - 1) / PRE_BLOCK;
+  GSAJ_HIP_CHECK(hipMemsetAsync(g.counters, 0, 64 * sizeof(uint32_t), s));
+  {
+    GsajProfScope ps(ST_PREPROCESS, s);
+    hipLaunchKernelGGL(k_preprocess, dim3(nblk), dim3(PRE_BLOCK), 0, s, p, radii, g);
+  }
+  {
+    GsajProfScope ps(ST_SCAN, s);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, nblk, g.block_sums, g.counters);
+  }
+  GSAJ_HIP_CHECK(hipGetLastError());
+  return GSAJ_OK;
+}
+
+int launch_emit_keys(int P, int grid_x, int grid_y, const int *radii, const GeomWS &g, const BinWS &b, hipStream_t s) {
+  const int nblk = (P + PRE_BLOCK - 1) / PRE_BLOCK;
+  {
+    GsajProfScope ps(ST_EMIT_KEYS, s);
+    hipLaunchKernelGGL(k_emit_keys, dim3(nblk), dim3(PRE_BLOCK), 0, s, P, grid_x, grid_y, radii, g, b.keys_unsorted,
+                       b.vals_unsorted);
+  }
+  GSAJ_HIP_CHECK(hipGetLastError());
+  return GSAJ_OK;
+}
+
+int launch_mark_visible(int P, const float *means3D, const float *viewmatrix, uint8_t *present, hipStream_t s) {
+  const int nblk = (P + PRE_BLOCK - 1) / PRE_BLOCK;
+  hipLaunchKernelGGL(k_mark_visible, dim3(nblk), dim3(PRE_BLOCK), 0, s, P, means3D, viewmatrix, present);
+  GSAJ_HIP_CHECK(hipGetLastError());
+  return GSAJ_OK;
+}

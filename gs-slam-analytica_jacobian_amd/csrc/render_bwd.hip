@@ -1,0 +1,174 @@
+// render_bwd.hip -- per-tile reverse compositor: per-pixel dL/dC, dL/dD -> per-instance
+// partial gradients of (mean2D, conic, opacity, colour, depth)  (gfx950).
+//
+// Semantics: backward.cu:648-872 (renderCUDA backward): walk the tile list back to front from
+// each pixel's last contributor, T <- T/(1-alpha), recurrences accum_rec / accum_rec_depth,
+// dL/dalpha incl. the background term, dL/dmean2D scaled by (W/2, H/2).
+//
+// MI355X design (differs from the reference on purpose):
+//  * the reference reduces the 10 per-pixel partials of EVERY list entry with a 256-thread
+//    shared-memory tree (8 barrier rounds, backward.cu:633-644) and then issues 10 global float
+//    atomics.  Here each wave64 (an 8x8 pixel quadrant) reduces its 10 partials in registers:
+//    v_permlane32_swap / v_permlane16_swap merge two registers per instruction across the
+//    half-wave and row boundaries (10 -> 5 -> 3 registers), then four DPP row rotations finish
+//    the 16-lane rows.  ~29 VALU ops per entry, no barrier, no LDS traffic for the reduction.
+//  * no global atomics at all: the four waves of a tile write their totals to private LDS slots,
+//    and after each round of BWD_ROUND entries the workgroup stores one 48-byte partial-gradient
+//    row per (tile, Gaussian) instance, coalesced, at the instance's sorted position.  The
+//    per-Gaussian kernel (gaussian_bwd.hip) sums a Gaussian's instances in a fixed order, so
+//    gradients are bit-reproducible run to run (the reference's float atomics are not).
+//  * entries beyond the quadrant's / tile's furthest last-contributor are never visited.
+#include "gsaj_common.h"
+#include "wave_reduce.h"
+
+#define BWD_ROUND 128
+
+__global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int gx, const uint2 *__restrict__ ranges,
+                                                    const float4 *__restrict__ records, const float *__restrict__ bg,
+                                                    const float *__restrict__ final_T,
+                                                    const uint32_t *__restrict__ n_contrib,
+                                                    const float *__restrict__ dL_dpix,
+                                                    const float *__restrict__ dL_dpix_depth,
+                                                    float4 *__restrict__ inst_grad) {
+  __shared__ float4 rec[BWD_ROUND * REC_F4];
+  __shared__ float acc[BWD_ROUND * 4 * IGRAD_F];  // [entry][wave][12]
+  __shared__ uint32_t wave_max[4];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tile = blockIdx.x;
+  const int ty = tile / gx, tx = tile - ty * gx;
+  const int px = tx * TILE + (wave & 1) * 8 + (lane & 7);
+  const int py = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
+  const bool inside = px < W && py < H;
+  const float pxf = (float)px, pyf = (float)py;
+  const uint2 range = ranges[tile];
+  const size_t pid = (size_t)py * W + px, HW = (size_t)H * W;
+
+  const float T_final = inside ? final_T[pid] : 0.f;
+  float T = T_final;
+  const uint32_t last = inside ? n_contrib[pid] : 0u;
+  float gC0 = 0.f, gC1 = 0.f, gC2 = 0.f, gD = 0.f;
+  if (inside) {
+    gC0 = dL_dpix[pid];
+    gC1 = dL_dpix[HW + pid];
+    gC2 = dL_dpix[2 * HW + pid];
+    gD = dL_dpix_depth[pid];
+  }
+  const float bg_dot = bg[0] * gC0 + bg[1] * gC1 + bg[2] * gC2;
+  const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
+
+  // furthest last-contributor of this quadrant and of the tile
+  uint32_t wmax = last;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, o));
+  if (lane == 0) wave_max[wave] = wmax;
+  __syncthreads();
+  const uint32_t bmax = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
+
+  float accC0 = 0.f, accC1 = 0.f, accC2 = 0.f, accD = 0.f;  // accum_rec, accum_rec_depth
+  float lastC0 = 0.f, lastC1 = 0.f, lastC2 = 0.f, lastD = 0.f, last_alpha = 0.f;
+
+  uint32_t hi = range.x + bmax;  // exclusive sorted position; rows [hi, range.y) stay zero
+  while (hi > range.x) {
+    const uint32_t lo = (hi - range.x > BWD_ROUND) ? hi - BWD_ROUND : range.x;
+    const int n = (int)(hi - lo);
+    if (tid < n) {
+      const float4 *src = records + (size_t)(lo + tid) * REC_F4;
+      rec[tid * REC_F4 + 0] = src[0];
+      rec[tid * REC_F4 + 1] = src[1];
+      rec[tid * REC_F4 + 2] = src[2];
+    }
+    {
+      float4 *z = reinterpret_cast<float4 *>(acc);
+      for (int i = tid; i < n * 4 * (IGRAD_F / 4); i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+
+    const uint32_t first_idx = lo - range.x;  // list index (0-based) of rec[0]
+    if (wmax > first_idx) {
+      for (int j = n - 1; j >= 0; --j) {
+        const uint32_t idx = first_idx + (uint32_t)j;
+        if (idx >= wmax) continue;
+        const float4 r0 = rec[j * REC_F4 + 0];
+        const float4 r1 = rec[j * REC_F4 + 1];
+        const float dx = r0.x - pxf, dy = r0.y - pyf;
+        const float power = -0.5f * (r1.x * dx * dx + r1.z * dy * dy) - r1.y * dx * dy;
+        const float G = __expf(power);
+        const float alpha = fminf(0.99f, r1.w * G);
+        const bool valid = idx < last && power <= 0.0f && alpha >= (1.0f / 255.0f);
+        if (__ballot(valid) == 0ull) continue;
+        const float4 r2 = rec[j * REC_F4 + 2];
+
+        const float inv1ma = __builtin_amdgcn_rcpf(1.f - alpha);
+        const float Tn = T * inv1ma;
+        const float dchannel = alpha * Tn;
+        const float one_m_la = 1.f - last_alpha;
+        const float aC0 = last_alpha * lastC0 + one_m_la * accC0;
+        const float aC1 = last_alpha * lastC1 + one_m_la * accC1;
+        const float aC2 = last_alpha * lastC2 + one_m_la * accC2;
+        const float aD = last_alpha * lastD + one_m_la * accD;
+        float dL_dalpha = (r2.x - aC0) * gC0 + (r2.y - aC1) * gC1 + (r2.z - aC2) * gC2 + (r0.z - aD) * gD;
+        dL_dalpha *= Tn;
+        dL_dalpha += (-T_final * inv1ma) * bg_dot;
+        const float dL_dG = r1.w * dL_dalpha;
+        const float gdx = G * dx, gdy = G * dy;
+        const float dG_ddelx = -gdx * r1.x - gdy * r1.y;
+        const float dG_ddely = -gdy * r1.z - gdx * r1.y;
+
+        float v[10];
+        v[0] = valid ? dL_dG * dG_ddelx * ddelx_dx : 0.f;
+        v[1] = valid ? dL_dG * dG_ddely * ddely_dy : 0.f;
+        v[2] = valid ? -0.5f * gdx * dx * dL_dG : 0.f;
+        v[3] = valid ? -0.5f * gdx * dy * dL_dG : 0.f;
+        v[4] = valid ? -0.5f * gdy * dy * dL_dG : 0.f;
+        v[5] = valid ? G * dL_dalpha : 0.f;
+        v[6] = valid ? dchannel * gC0 : 0.f;
+        v[7] = valid ? dchannel * gC1 : 0.f;
+        v[8] = valid ? dchannel * gC2 : 0.f;
+        v[9] = valid ? dchannel * gD : 0.f;
+        if (valid) {
+          T = Tn;
+          accC0 = aC0; accC1 = aC1; accC2 = aC2; accD = aD;
+          lastC0 = r2.x; lastC1 = r2.y; lastC2 = r2.z; lastD = r0.z;
+          last_alpha = alpha;
+        }
+
+        // ---- wave reduction of the 10 partials (registers only), totals -> this wave's LDS slot ----
+        float x0, x1, x2;
+        reduce10(v, x0, x1, x2);
+        store10(acc + (j * 4 + wave) * IGRAD_F, lane, x0, x1, x2);
+      }
+    }
+    __syncthreads();
+    if (tid < n) {
+      const float4 *a = reinterpret_cast<const float4 *>(acc) + tid * 4 * (IGRAD_F / 4);
+      float4 s0 = a[0], s1 = a[1], s2 = a[2];
+#pragma unroll
+      for (int w = 1; w < 4; w++) {
+        const float4 b0 = a[w * 3 + 0], b1 = a[w * 3 + 1], b2 = a[w * 3 + 2];
+        s0.x += b0.x; s0.y += b0.y; s0.z += b0.z; s0.w += b0.w;
+        s1.x += b1.x; s1.y += b1.y; s1.z += b1.z; s1.w += b1.w;
+        s2.x += b2.x; s2.y += b2.y;
+      }
+      s2.z = 0.f; s2.w = 0.f;
+      float4 *dst = inst_grad + (size_t)(lo + tid) * REC_F4;
+      dst[0] = s0;
+      dst[1] = s1;
+      dst[2] = s2;
+    }
+    __syncthreads();
+    hi = lo;
+  }
+}
+
+int launch_render_backward(int R, int W, int H, int grid_x, int grid_y, const float *bg, const BinWS &b,
+                           const ImageWS &im, const float *dL_dpix, const float *dL_dpix_depth, hipStream_t s) {
+  if (R <= 0) return GSAJ_OK;
+  GSAJ_HIP_CHECK(hipMemsetAsync(b.inst_grad, 0, sizeof(float4) * REC_F4 * (size_t)R, s));
+  {
+    GsajProfScope ps(ST_RENDER_BWD, s);
+    hipLaunchKernelGGL(k_render_bwd, dim3(grid_x * grid_y), dim3(256), 0, s, W, H, grid_x, im.ranges, b.records, bg,
+                     im.final_T, im.n_contrib, dL_dpix, dL_dpix_depth, b.inst_grad);
+  }
+  GSAJ_HIP_CHECK(hipGetLastError());
+  return GSAJ_OK;
+}

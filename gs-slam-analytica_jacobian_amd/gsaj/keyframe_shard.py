@@ -1,0 +1,69 @@
+"""Multi-GPU sharding of the mapping window: independent keyframes of one shared Gaussian map.
+
+The reference is single-GPU; its mapping step renders every keyframe of the window, sums the
+losses and back-propagates once, so per-Gaussian gradients ACCUMULATE over keyframes while each
+keyframe's dL/dtau stays its own (utils/slam_backend.py:168-232, SURVEY 8e partitioning A).
+On an 8-GPU MI355X node: replicate the Gaussians, deal keyframes round-robin over the ranks
+(one process per GPU), run forward + analytical backward locally, then
+  * ONE all-reduce(sum) of the flat per-Gaussian gradient bucket (the kernels write straight into
+    it -- no packing pass); RCCL over xGMI, backend "nccl" (= RCCL on ROCm), "gloo" in CPU tests;
+  * ONE all-gather of the [k_local, 6] pose gradients (each keyframe's dL/dtau belongs to it).
+No collective sits inside the per-frame data path.
+"""
+import torch
+import torch.distributed as dist
+
+# per-Gaussian gradient fields of the bucket, in order, as (name, floats per Gaussian)
+def bucket_layout(M, has_scales=True):
+    fields = [("mean3D", 3), ("sh", 3 * M), ("opacity", 1)]
+    if has_scales:
+        fields += [("scale", 3), ("rot", 4)]
+    else:
+        fields += [("cov3D", 6)]
+    return fields
+
+
+def bucket_views(bucket, P, M, has_scales=True):
+    """Split a flat [P * sum(widths)] tensor into per-field [P, w] views (field-major, so each
+    field is one contiguous region the kernels can write)."""
+    out, off = {}, 0
+    for name, w in bucket_layout(M, has_scales):
+        out[name] = bucket[off:off + P * w].view(P, w)
+        off += P * w
+    assert off == bucket.numel()
+    return out
+
+
+def bucket_numel(P, M, has_scales=True):
+    return P * sum(w for _, w in bucket_layout(M, has_scales))
+
+
+def shard_keyframes(n_keyframes, world_size, rank):
+    """Round-robin ownership: keyframe k belongs to rank k % world_size."""
+    return list(range(rank, n_keyframes, world_size))
+
+
+def allreduce_gaussian_grads(bucket, group=None):
+    """Sum the per-Gaussian gradient bucket over all ranks in place (one collective)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
+    return bucket
+
+
+def gather_pose_grads(tau_local, n_keyframes, group=None):
+    """tau_local: [k_local, 6] in the order of shard_keyframes(); returns [n_keyframes, 6] with
+    row k = dL/dtau of keyframe k on every rank.  Ranks may own different numbers of keyframes:
+    rows are padded to the maximum and scattered back by owner."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return tau_local.clone()
+    world = dist.get_world_size(group)
+    k_max = (n_keyframes + world - 1) // world
+    pad = torch.zeros((k_max, 6), dtype=tau_local.dtype, device=tau_local.device)
+    pad[: tau_local.shape[0]] = tau_local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    out = torch.zeros((n_keyframes, 6), dtype=tau_local.dtype, device=tau_local.device)
+    for r in range(world):
+        ks = shard_keyframes(n_keyframes, world, r)
+        out[ks] = parts[r][: len(ks)]
+    return out

@@ -1,0 +1,308 @@
+"""Torch-tensor front end of the C ABI: the three functions the reference's pybind module
+exports (submodules/diff-gaussian-rasterization/ext.cpp:15-19) with the same argument
+order and return tuples (rasterize_points.cu:36-246), backed by libgsaj_hip.so.
+
+PyTorch only provides device memory and the current HIP stream here; every computation
+happens in the hand-written kernels.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+_F32 = torch.float32
+
+
+def _ptr(t):
+    """Device pointer of a tensor, NULL for None / empty tensors (the reference passes empty
+    tensors for absent optionals, diff_gaussian_rasterization/__init__.py:229-243)."""
+    if t is None or t.numel() == 0:
+        return None
+    return t.data_ptr()
+
+
+def _prep(t, device, name):
+    if t is None or t.numel() == 0:
+        return None
+    if t.device != device:
+        t = t.to(device)
+    if t.dtype != _F32:
+        t = t.to(_F32)
+    return t.contiguous()
+
+
+def _stream(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _require_cuda(t, what):
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on the GPU (HIP device): libgsaj_hip has no CPU path" % what)
+
+
+def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                        viewmatrix, projmatrix, projmatrix_raw, tan_fovx, tan_fovy, image_height, image_width, sh,
+                        degree, campos, prefiltered, debug):
+    """-> (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, depth, opacity, n_touched)
+    (RasterizeGaussiansCUDA, rasterize_points.cu:36-130)."""
+    lib = _lib.load()
+    if means3D.ndim != 2 or means3D.shape[1] != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    _require_cuda(means3D, "means3D")
+    dev = means3D.device
+    P, H, W = means3D.shape[0], int(image_height), int(image_width)
+    f = dict(device=dev, dtype=_F32)
+    out_color = torch.zeros((3, H, W), **f)
+    out_depth = torch.zeros((1, H, W), **f)
+    out_opacity = torch.zeros((1, H, W), **f)
+    radii = torch.zeros((P,), device=dev, dtype=torch.int32)
+    n_touched = torch.zeros((P,), device=dev, dtype=torch.int32)
+    byte = dict(device=dev, dtype=torch.uint8)
+    if P == 0:
+        e = torch.empty(0, **byte)
+        return 0, out_color, radii, e, e.clone(), e.clone(), out_depth, out_opacity, n_touched
+
+    means3D = _prep(means3D, dev, "means3D")
+    colors = _prep(colors, dev, "colors")
+    opacity = _prep(opacity, dev, "opacity")
+    scales = _prep(scales, dev, "scales")
+    rotations = _prep(rotations, dev, "rotations")
+    cov3D_precomp = _prep(cov3D_precomp, dev, "cov3D")
+    sh = _prep(sh, dev, "sh")
+    background = _prep(background, dev, "bg")
+    viewmatrix = _prep(viewmatrix, dev, "viewmatrix")
+    projmatrix = _prep(projmatrix, dev, "projmatrix")
+    campos = _prep(campos, dev, "campos")
+    M = 0 if sh is None else sh.shape[1]
+
+    geom = torch.empty(lib.gsaj_geom_workspace_bytes(P), **byte)
+    img = torch.empty(lib.gsaj_image_workspace_bytes(W, H), **byte)
+    st = _stream(dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gsaj_forward_preprocess(
+            P, int(degree), M, W, H, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales),
+            float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix),
+            _ptr(campos), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), radii.data_ptr(), geom.data_ptr(),
+            st), "gsaj_forward_preprocess")
+        R = ctypes.c_int(0)
+        _lib.check(lib.gsaj_forward_num_rendered(P, geom.data_ptr(), st, ctypes.byref(R)), "gsaj_forward_num_rendered")
+        R = R.value
+        nbytes = lib.gsaj_binning_workspace_bytes(R)
+        binning = torch.empty(nbytes, **byte)
+        _lib.check(lib.gsaj_forward_render(
+            P, R, W, H, _ptr(background), _ptr(colors), radii.data_ptr(), geom.data_ptr(), binning.data_ptr(), nbytes,
+            img.data_ptr(), out_color.data_ptr(), out_depth.data_ptr(), out_opacity.data_ptr(), n_touched.data_ptr(),
+            st), "gsaj_forward_render")
+        if debug:
+            torch.cuda.synchronize(dev)
+    return R, out_color, radii, geom, binning, img, out_depth, out_opacity, n_touched
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+                                 viewmatrix, projmatrix, projmatrix_raw, tan_fovx, tan_fovy, dL_dout_color,
+                                 dL_dout_depths, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug,
+                                 per_gaussian_tau=True):
+    """-> (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dtau)
+    (RasterizeGaussiansBackwardCUDA, rasterize_points.cu:132-223) followed by three extras: dL_dtau_sum [6]
+    (= torch.sum(grad_tau.view(-1, 6), dim=0) of diff_gaussian_rasterization/__init__.py:162, reduced in-kernel),
+    dL_dconic [P,2,2] and dL_ddepths [P,1] (internal to the reference's binding; exposed for parity tests)."""
+    lib = _lib.load()
+    _require_cuda(means3D, "means3D")
+    dev = means3D.device
+    P = means3D.shape[0]
+    H, W = dL_dout_color.shape[1], dL_dout_color.shape[2]
+    sh = _prep(sh, dev, "sh")
+    M = 0 if sh is None else sh.shape[1]
+    f = dict(device=dev, dtype=_F32)
+    dL_dmeans3D = torch.empty((P, 3), **f)
+    dL_dmeans2D = torch.empty((P, 3), **f)
+    dL_dcolors = torch.empty((P, 3), **f)
+    dL_ddepths = torch.empty((P, 1), **f)
+    dL_dconic = torch.empty((P, 2, 2), **f)
+    dL_dopacity = torch.empty((P, 1), **f)
+    dL_dcov3D = torch.empty((P, 6), **f)
+    dL_dsh = torch.empty((P, M, 3), **f)
+    dL_dscales = torch.empty((P, 3), **f)
+    dL_drotations = torch.empty((P, 4), **f)
+    dL_dtau = torch.empty((P, 6), **f) if per_gaussian_tau else None
+    dL_dtau_sum = torch.zeros((6,), **f)
+    if P == 0:
+        return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations,
+                dL_dtau, dL_dtau_sum, dL_dconic, dL_ddepths)
+    means3D = _prep(means3D, dev, "means3D")
+    colors = _prep(colors, dev, "colors")
+    scales = _prep(scales, dev, "scales")
+    rotations = _prep(rotations, dev, "rotations")
+    cov3D_precomp = _prep(cov3D_precomp, dev, "cov3D")
+    background = _prep(background, dev, "bg")
+    viewmatrix = _prep(viewmatrix, dev, "viewmatrix")
+    projmatrix = _prep(projmatrix, dev, "projmatrix")
+    projmatrix_raw = _prep(projmatrix_raw, dev, "projmatrix_raw")
+    campos = _prep(campos, dev, "campos")
+    dL_dout_color = _prep(dL_dout_color, dev, "dL_dout_color")
+    dL_dout_depths = _prep(dL_dout_depths, dev, "dL_dout_depths")
+    st = _stream(dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gsaj_rasterize_backward(
+            P, int(degree), M, int(R), _ptr(background), W, H, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(scales),
+            float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix),
+            _ptr(projmatrix_raw), _ptr(campos), float(tan_fovx), float(tan_fovy), radii.data_ptr(),
+            geomBuffer.data_ptr(), binningBuffer.data_ptr(), imageBuffer.data_ptr(), _ptr(dL_dout_color),
+            _ptr(dL_dout_depths), dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(),
+            dL_dcolors.data_ptr(), dL_ddepths.data_ptr(), dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(),
+            _ptr(dL_dsh), _ptr(dL_dscales) if scales is not None else None,
+            _ptr(dL_drotations) if rotations is not None else None,
+            dL_dtau.data_ptr() if dL_dtau is not None else None, dL_dtau_sum.data_ptr(), st), "gsaj_rasterize_backward")
+        if debug:
+            torch.cuda.synchronize(dev)
+    if scales is None:
+        dL_dscales.zero_()
+        dL_drotations.zero_()
+    return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dtau,
+            dL_dtau_sum, dL_dconic, dL_ddepths)
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    """-> bool [P] (markVisible, rasterize_points.cu:225-246)."""
+    lib = _lib.load()
+    _require_cuda(means3D, "means3D")
+    dev = means3D.device
+    P = means3D.shape[0]
+    present = torch.zeros((P,), device=dev, dtype=torch.bool)
+    if P != 0:
+        means3D = _prep(means3D, dev, "means3D")
+        viewmatrix = _prep(viewmatrix, dev, "viewmatrix")
+        projmatrix = _prep(projmatrix, dev, "projmatrix")
+        with torch.cuda.device(dev):
+            _lib.check(lib.gsaj_mark_visible(P, _ptr(means3D), _ptr(viewmatrix), _ptr(projmatrix), present.data_ptr(),
+                                             _stream(dev)), "gsaj_mark_visible")
+    return present
+
+
+def debug_export(P, R, W, H, geomBuffer, binningBuffer, imageBuffer):
+    """Internal forward state as tensors (parity tests)."""
+    lib = _lib.load()
+    dev = geomBuffer.device
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    f = dict(device=dev, dtype=_F32)
+    out = dict(
+        means2D=torch.zeros((P, 2), **f), depths=torch.zeros((P,), **f), cov3D=torch.zeros((P, 6), **f),
+        conic_opacity=torch.zeros((P, 4), **f), rgb=torch.zeros((P, 3), **f),
+        clamped=torch.zeros((P, 3), device=dev, dtype=torch.uint8),
+        tiles_touched=torch.zeros((P,), device=dev, dtype=torch.int32),
+        point_list=torch.zeros((max(R, 1),), device=dev, dtype=torch.int32),
+        ranges=torch.zeros((tiles, 2), device=dev, dtype=torch.int32), final_T=torch.zeros((H, W), **f),
+        n_contrib=torch.zeros((H, W), device=dev, dtype=torch.int32))
+    with torch.cuda.device(dev):
+        _lib.check(lib.gsaj_debug_export(
+            P, R, W, H, geomBuffer.data_ptr(), binningBuffer.data_ptr(), imageBuffer.data_ptr(),
+            out["means2D"].data_ptr(), out["depths"].data_ptr(), out["cov3D"].data_ptr(),
+            out["conic_opacity"].data_ptr(), out["rgb"].data_ptr(), out["clamped"].data_ptr(),
+            out["tiles_touched"].data_ptr(), out["point_list"].data_ptr(), out["ranges"].data_ptr(),
+            out["final_T"].data_ptr(), out["n_contrib"].data_ptr(), _stream(dev)), "gsaj_debug_export")
+    out["point_list"] = out["point_list"][:R]
+    return out
+
+
+STAGE_NAMES = ("preprocess,scan_blocks,emit_keys,sort,ranges_records,render_fwd,render_bwd,gaussian_bwd,tau_finalize,"
+               "dense_bwd,dense_reduce").split(",")
+
+
+class profile_stages:
+    """Context manager around gsaj_profile_begin/_end: per-stage kernel time (ms) and launch
+    counts measured with HIP events on the launch stream."""
+
+    def __init__(self, max_records=4096):
+        self.max_records = max_records
+        self.ms, self.launches = {}, {}
+
+    def __enter__(self):
+        _lib.check(_lib.load().gsaj_profile_begin(self.max_records), "gsaj_profile_begin")
+        return self
+
+    def __exit__(self, *exc):
+        n = len(STAGE_NAMES)
+        ms = (ctypes.c_float * n)()
+        cnt = (ctypes.c_int * n)()
+        _lib.check(_lib.load().gsaj_profile_end(ctypes.cast(ms, ctypes.c_void_p), ctypes.cast(cnt, ctypes.c_void_p)),
+                   "gsaj_profile_end")
+        self.ms = {k: float(ms[i]) for i, k in enumerate(STAGE_NAMES)}
+        self.launches = {k: int(cnt[i]) for i, k in enumerate(STAGE_NAMES)}
+        return False
+
+
+class FrameContext:
+    """Pre-allocated outputs and workspaces for repeated forward+backward passes over one scene
+    size (the tracking / mapping inner loop): no allocation and two C-ABI calls per step.
+    The binning workspace grows geometrically when a frame produces more instances."""
+
+    def __init__(self, P, W, H, M, device, has_scales=True, per_gaussian_tau=False):
+        lib = _lib.load()
+        self.lib, self.P, self.W, self.H, self.M, self.dev = lib, P, W, H, M, torch.device(device)
+        f = dict(device=self.dev, dtype=_F32)
+        byte = dict(device=self.dev, dtype=torch.uint8)
+        self.color = torch.zeros((3, H, W), **f)
+        self.depth = torch.zeros((1, H, W), **f)
+        self.opacity = torch.zeros((1, H, W), **f)
+        self.radii = torch.zeros((P,), device=self.dev, dtype=torch.int32)
+        self.n_touched = torch.zeros((P,), device=self.dev, dtype=torch.int32)
+        self.geom = torch.empty(lib.gsaj_geom_workspace_bytes(P), **byte)
+        self.img = torch.empty(lib.gsaj_image_workspace_bytes(W, H), **byte)
+        self.binning = torch.empty(0, **byte)
+        self.R = 0
+        # per-Gaussian parameter gradients live in ONE flat bucket (field-major) so that a multi-GPU
+        # mapping step can all-reduce it with a single collective (gsaj.keyframe_shard)
+        from .keyframe_shard import bucket_numel, bucket_views
+        self.bucket = torch.zeros(bucket_numel(P, M, has_scales), **f)
+        v = bucket_views(self.bucket, P, M, has_scales)
+        self.g = dict(
+            mean2D=torch.zeros((P, 3), **f), conic=torch.zeros((P, 2, 2), **f), opacity=v["opacity"],
+            color=torch.zeros((P, 3), **f), depth=torch.zeros((P, 1), **f), mean3D=v["mean3D"],
+            cov3D=v["cov3D"] if not has_scales else torch.zeros((P, 6), **f), sh=v["sh"].view(P, M, 3),
+            scale=v.get("scale"), rot=v.get("rot"),
+            tau=torch.zeros((P, 6), **f) if per_gaussian_tau else None, tau_sum=torch.zeros((6,), **f))
+
+    def _ensure_binning(self, R):
+        need = self.lib.gsaj_binning_workspace_bytes(R)
+        if self.binning.numel() < need:
+            self.binning = torch.empty(int(need * 1.25) + 4096, device=self.dev, dtype=torch.uint8)
+
+    def forward(self, bg, means3D, opacities, viewmatrix, projmatrix, campos, tanfovx, tanfovy, sh_degree=0, shs=None,
+                colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, scale_modifier=1.0):
+        lib, st = self.lib, _stream(self.dev)
+        _lib.check(lib.gsaj_forward_preprocess(
+            self.P, int(sh_degree), self.M, self.W, self.H, _ptr(means3D), _ptr(shs), _ptr(colors_precomp),
+            _ptr(opacities), _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix),
+            _ptr(projmatrix), _ptr(campos), float(tanfovx), float(tanfovy), 0, self.radii.data_ptr(),
+            self.geom.data_ptr(), st), "gsaj_forward_preprocess")
+        R = ctypes.c_int(0)
+        _lib.check(lib.gsaj_forward_num_rendered(self.P, self.geom.data_ptr(), st, ctypes.byref(R)),
+                   "gsaj_forward_num_rendered")
+        self.R = R.value
+        self._ensure_binning(self.R)
+        _lib.check(lib.gsaj_forward_render(
+            self.P, self.R, self.W, self.H, _ptr(bg), _ptr(colors_precomp), self.radii.data_ptr(), self.geom.data_ptr(),
+            self.binning.data_ptr(), self.binning.numel(), self.img.data_ptr(), self.color.data_ptr(),
+            self.depth.data_ptr(), self.opacity.data_ptr(), self.n_touched.data_ptr(), st), "gsaj_forward_render")
+        return self.R
+
+    def backward(self, bg, means3D, viewmatrix, projmatrix, projmatrix_raw, campos, tanfovx, tanfovy, dL_dcolor, dL_ddepth,
+                 sh_degree=0, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None,
+                 scale_modifier=1.0):
+        g = self.g
+        _lib.check(self.lib.gsaj_rasterize_backward(
+            self.P, int(sh_degree), self.M, self.R, _ptr(bg), self.W, self.H, _ptr(means3D), _ptr(shs),
+            _ptr(colors_precomp), _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp),
+            _ptr(viewmatrix), _ptr(projmatrix), _ptr(projmatrix_raw), _ptr(campos), float(tanfovx), float(tanfovy),
+            self.radii.data_ptr(), self.geom.data_ptr(), self.binning.data_ptr(), self.img.data_ptr(), _ptr(dL_dcolor),
+            _ptr(dL_ddepth), g["mean2D"].data_ptr(), g["conic"].data_ptr(), g["opacity"].data_ptr(),
+            g["color"].data_ptr(), g["depth"].data_ptr(), g["mean3D"].data_ptr(), g["cov3D"].data_ptr(), _ptr(g["sh"]),
+            _ptr(g["scale"]), _ptr(g["rot"]), _ptr(g["tau"]), g["tau_sum"].data_ptr(), _stream(self.dev)),
+            "gsaj_rasterize_backward")
+        return g
+
+    def interactions(self):
+        """sum over pixels of n_contrib = Gaussian-pixel interactions of the last forward."""
+        dbg = debug_export(self.P, self.R, self.W, self.H, self.geom, self.binning, self.img)
+        return int(dbg["n_contrib"].to(torch.int64).sum().item())

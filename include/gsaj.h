@@ -1,0 +1,167 @@
+/*
+ * gsaj.h -- C ABI of libgsaj_hip.so: MI355X (gfx950) Gaussian-splat rasteriser with
+ * analytical pose Jacobians.
+ *
+ * These entry points are what the reference's Python binding for this path would bind in
+ * place of its pybind/CUDA layer (paths relative to the reference repository):
+ *
+ *   gsaj_rasterize_forward  / gsaj_forward_*   <- CudaRasterizer::Rasterizer::forward
+ *        submodules/diff-gaussian-rasterization/cuda_rasterizer/rasterizer.h:33-58,
+ *        called from rasterize_points.cu:36-130 (RasterizeGaussiansCUDA)
+ *   gsaj_rasterize_backward                    <- CudaRasterizer::Rasterizer::backward
+ *        rasterizer.h:60-91, called from rasterize_points.cu:132-223
+ *   gsaj_mark_visible                          <- CudaRasterizer::Rasterizer::markVisible
+ *        rasterizer.h:24-31, rasterize_points.cu:225-246
+ *   gsaj_*_workspace_bytes                     <- required<GeometryState/ImageState/BinningState>()
+ *        rasterizer_impl.h:21-72 (the std::function<char*(size_t)> resize callbacks of
+ *        rasterize_points.cu:27-33 become size queries + caller-owned buffers)
+ *   gsaj_dense_* / gsaj_pose_jacobians         <- the CPU/NumPy analytic path
+ *        Loss_Derivative_script_compare.py:1173-1351 (compute_gradients_2D_vectorized_chunked),
+ *        :633-760 (GetAnalyticalJcobian, compute_analytical_jacobians_all_gaussians),
+ *        :1587-1695 (dL/dtau assembly)
+ *
+ * Conventions
+ *   - every pointer marked "dev" is a device (HBM) pointer; fp32, contiguous, caller-owned.
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream).  All work is
+ *     enqueued asynchronously on it; the only host synchronisation is the 4-byte read of
+ *     the instance count in gsaj_forward_num_rendered / gsaj_rasterize_forward
+ *     (the reference has the same one, rasterizer_impl.cu:331).
+ *   - viewmatrix / projmatrix / projmatrix_raw are 16 floats = the transposed 4x4 tensors
+ *     the reference hands over (W2C^T, (P W2C)^T, P^T), i.e. column-major W2C / P W2C / P.
+ *   - return value: >= 0 on success (gsaj_rasterize_forward returns num_rendered),
+ *     a negative GSAJ_ERR_* on failure; gsaj_last_error() describes the last failure of
+ *     the calling thread.
+ *   - outputs that kernels accumulate into (n_touched, every dL_d*) are zeroed by the
+ *     library, as the reference's binding does (rasterize_points.cu:84-88,175-185).
+ */
+#ifndef GSAJ_H_INCLUDED
+#define GSAJ_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSAJ_OK 0
+#define GSAJ_ERR_INVALID_ARGUMENT (-1)   /* bad shape / null pointer / bad combination */
+#define GSAJ_ERR_HIP (-2)                /* a HIP runtime call failed */
+#define GSAJ_ERR_WORKSPACE_TOO_SMALL (-3) /* binning workspace smaller than gsaj_binning_workspace_bytes(R) */
+#define GSAJ_ERR_PREFILTERED_CULLED (-4) /* prefiltered=1 but a point failed the frustum test (auxiliary.h:156-160) */
+
+#define GSAJ_TILE 16         /* BLOCK_X = BLOCK_Y of config.h:15-17 */
+#define GSAJ_NUM_CHANNELS 3  /* NUM_CHANNELS of config.h */
+
+const char *gsaj_last_error(void);
+int gsaj_version(void);
+
+/* ---- workspace sizes (bytes) -------------------------------------------------------- */
+size_t gsaj_geom_workspace_bytes(int P);
+size_t gsaj_image_workspace_bytes(int W, int H);
+size_t gsaj_binning_workspace_bytes(int R);
+
+/* ---- forward, two-phase form --------------------------------------------------------- */
+/* Phase A: per-Gaussian projection (cov3D, EWA cov2D + 0.3, conic, radius, tile rect,
+ * SH -> RGB) and the prefix sum of tiles touched.  Writes radii[P] (int32, may be NULL). */
+int gsaj_forward_preprocess(int P, int D, int M, int W, int H,
+                            const float *means3D /*dev [P,3]*/, const float *shs /*dev [P,M,3] or NULL*/,
+                            const float *colors_precomp /*dev [P,3] or NULL*/, const float *opacities /*dev [P]*/,
+                            const float *scales /*dev [P,3] or NULL*/, float scale_modifier,
+                            const float *rotations /*dev [P,4] or NULL*/, const float *cov3D_precomp /*dev [P,6] or NULL*/,
+                            const float *viewmatrix /*dev [16]*/, const float *projmatrix /*dev [16]*/,
+                            const float *campos /*dev [3]*/, float tanfovx, float tanfovy, int prefiltered,
+                            int *radii /*dev [P] or NULL*/, void *geom_ws /*dev*/, void *stream);
+/* Blocking: number of (Gaussian, tile) instances produced by phase A. */
+int gsaj_forward_num_rendered(int P, const void *geom_ws, void *stream, int *num_rendered /*host*/);
+/* Phase B: key emission, (tile, depth) sort, tile ranges, per-instance record gather,
+ * front-to-back compositing.  out_color [3,H,W], out_depth [1,H,W], out_opacity [1,H,W],
+ * n_touched [P] int32.  R must be the value phase A produced. */
+int gsaj_forward_render(int P, int R, int W, int H, const float *bg /*dev [3]*/,
+                        const float *colors_precomp /*dev [P,3] or NULL*/, const int *radii /*dev [P] or NULL*/,
+                        void *geom_ws, void *binning_ws, size_t binning_ws_bytes, void *image_ws,
+                        float *out_color, float *out_depth, float *out_opacity, int *n_touched, void *stream);
+
+/* ---- forward, one call (phase A, sync, phase B).  The caller supplies a binning
+ * workspace of any capacity; if it is too small the call fails with
+ * GSAJ_ERR_WORKSPACE_TOO_SMALL and *num_rendered_out holds the R to size it for. */
+int gsaj_rasterize_forward(int P, int D, int M, const float *bg, int W, int H,
+                           const float *means3D, const float *shs, const float *colors_precomp,
+                           const float *opacities, const float *scales, float scale_modifier,
+                           const float *rotations, const float *cov3D_precomp,
+                           const float *viewmatrix, const float *projmatrix, const float *campos,
+                           float tanfovx, float tanfovy, int prefiltered,
+                           float *out_color, float *out_depth, float *out_opacity, int *radii, int *n_touched,
+                           void *geom_ws, void *binning_ws, size_t binning_ws_bytes, void *image_ws,
+                           int *num_rendered_out /*host, may be NULL*/, void *stream);
+
+/* ---- backward ------------------------------------------------------------------------ */
+/* dL_dpix [3,H,W], dL_dpix_depth [1,H,W] -> dL_dmean2D [P,3] (NDC-scaled, z unused),
+ * dL_dconic [P,2,2] (slots 0,1,3), dL_dopacity [P], dL_dcolor [P,3], dL_ddepth [P],
+ * dL_dmean3D [P,3], dL_dcov3D [P,6], dL_dsh [P,M,3], dL_dscale [P,3], dL_drot [P,4],
+ * dL_dtau [P,6] (may be NULL) and dL_dtau_sum [6] = sum over Gaussians, tau = [rho, theta]
+ * (may be NULL; replaces torch.sum in diff_gaussian_rasterization/__init__.py:162).
+ * The three workspaces must be the ones the forward filled. */
+int gsaj_rasterize_backward(int P, int D, int M, int R, const float *bg, int W, int H,
+                            const float *means3D, const float *shs, const float *colors_precomp,
+                            const float *scales, float scale_modifier, const float *rotations,
+                            const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix,
+                            const float *projmatrix_raw, const float *campos, float tanfovx, float tanfovy,
+                            const int *radii, void *geom_ws, void *binning_ws, void *image_ws,
+                            const float *dL_dpix, const float *dL_dpix_depth,
+                            float *dL_dmean2D, float *dL_dconic, float *dL_dopacity, float *dL_dcolor,
+                            float *dL_ddepth, float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh,
+                            float *dL_dscale, float *dL_drot, float *dL_dtau, float *dL_dtau_sum, void *stream);
+
+/* ---- frustum test -------------------------------------------------------------------- */
+int gsaj_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix,
+                      uint8_t *present /*dev [P]*/, void *stream);
+
+/* ---- introspection of the forward state (parity tests, debugging) -------------------- */
+/* Copies internal arrays to caller-provided DEVICE buffers; any pointer may be NULL.
+ * means2D [P,2], depths [P], cov3D [P,6], conic_opacity [P,4], rgb [P,3], clamped [P,3] u8,
+ * tiles_touched [P] u32, point_list [R] u32, ranges [tiles,2] u32, final_T [H,W], n_contrib [H,W] u32. */
+int gsaj_debug_export(int P, int R, int W, int H, const void *geom_ws, const void *binning_ws, const void *image_ws,
+                      float *means2D, float *depths, float *cov3D, float *conic_opacity, float *rgb, uint8_t *clamped,
+                      uint32_t *tiles_touched, uint32_t *point_list, uint32_t *ranges, float *final_T,
+                      uint32_t *n_contrib, void *stream);
+
+/* ---- per-kernel timing (bench.py's roofline leg) ----------------------------------------
+ * Between gsaj_profile_begin and gsaj_profile_end every kernel launch of the library is
+ * bracketed by HIP events on the stream it is launched on.  gsaj_profile_end synchronises,
+ * and returns per stage the summed duration in ms and the number of launches.
+ * Stage order: GSAJ_STAGE_NAMES. */
+#define GSAJ_NUM_STAGES 11
+#define GSAJ_STAGE_NAMES "preprocess,scan_blocks,emit_keys,sort,ranges_records,render_fwd,render_bwd,gaussian_bwd,tau_finalize,dense_bwd,dense_reduce"
+int gsaj_profile_begin(int max_records);
+int gsaj_profile_end(float *stage_ms /*host [GSAJ_NUM_STAGES]*/, int *stage_launches /*host [GSAJ_NUM_STAGES]*/);
+
+/* ---- dense analytic path (NumPy-path semantics) ------------------ */
+size_t gsaj_dense_workspace_bytes(int N, int W, int H);
+/* N depth-sorted Gaussians: means2D [N,2] (pixels), covs2D [N,2,2], colors [N,3], depths [N], opac [N];
+ * per-pixel seeds seed_color [H,W,3], seed_depth [H,W]  ->
+ * grad_mu [N,2], grad_Sigma [N,2,2], grad_depth [N], grad_color [N,3]. */
+int gsaj_dense_backward(int N, int W, int H, const float *means2D, const float *covs2D, const float *colors,
+                        const float *depths, const float *opac, const float *seed_color, const float *seed_depth,
+                        float *grad_mu, float *grad_Sigma, float *grad_depth, float *grad_color,
+                        void *dense_ws, void *stream);
+/* Dense forward compositor: out_color [H,W,3], out_depth [H,W]. */
+int gsaj_dense_render(int N, int W, int H, const float *means2D, const float *covs2D, const float *colors,
+                      const float *depths, const float *opac, float *out_color, float *out_depth, void *stream);
+/* Closed-form d(mu_I)/d(tau) [N,2,6] and d(vec Sigma_I)/d(tau) [N,4,6] (fp64), already
+ * scaled to NDC / pixel^2 units like compute_analytical_jacobians_all_gaussians.
+ * T_cw: 16 doubles row-major; mu_w [N,3] doubles; cov3D [N,6] doubles. */
+int gsaj_pose_jacobians(int N, const double *T_cw /*dev*/, const double *mu_w, const double *cov3D, double fx,
+                        double fy, int W, int H, double *dmu_dtau, double *dcov_dtau, void *stream);
+/* dL/dtau (6 doubles, dev) of the NumPy path: chain rule over sorted Gaussians
+ * (order[i] = original index of sorted position i) including depth and SH view-direction terms. */
+int gsaj_dense_tau(int N, int sh_coeffs, int sh_degree, const int *order, const float *grad_mu,
+                   const float *grad_Sigma, const float *grad_depth, const float *grad_color,
+                   const double *dmu_dtau, const double *dcov_dtau, const double *mu_w, const double *T_cw,
+                   const double *campos, const double *shs /*[N,sh_coeffs,3]*/, double *dL_dtau /*dev [6]*/,
+                   double *parts /*dev [4,6] mu,cov,depth,sh or NULL*/, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSAJ_H_INCLUDED */
