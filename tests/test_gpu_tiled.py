@@ -53,7 +53,7 @@ def test_forward_and_backward_parity(torch_cuda, name, precomp):
     assert np.abs(n_touched.cpu().numpy().astype(np.int64) - ref["n_touched"]).sum() <= max(2, 1e-4 * ref["n_touched"].sum())
     for got, want in ((color, ref["color"]), (depth, ref["depth"]), (opacity, ref["opacity"]), (dbg["final_T"], st["final_T"])):
         got = got.cpu().numpy() if hasattr(got, "cpu") else got
-        assert hp.rel_err(got.reshape(want.shape), want) < IMG_TOL
+        hp.assert_image_close(got.reshape(want.shape), want, IMG_TOL)
 
     dLc, dLd = hp.seeds(cam, seed=1)
     gref = __import__("oracle.oracle", fromlist=["backward"]).backward(st, dLc, dLd, cam["projmatrix_raw"])
@@ -160,7 +160,7 @@ def test_render_api_autograd_and_pose_update(torch_cuda):
     ref, st = orc.forward(f(model.get_xyz), f(model.get_opacity), f(view.world_view_transform), f(view.full_proj_transform),
                           f(view.camera_center), cam["tanfovx"], cam["tanfovy"], cam["W"], cam["H"], np.zeros(3, np.float32),
                           shs=f(model.get_features), scales=f(model.get_scaling), rotations=f(model.get_rotation), sh_degree=3)
-    assert hp.rel_err(f(pkg["render"]), ref["color"]) < IMG_TOL
+    hp.assert_image_close(f(pkg["render"]), ref["color"], IMG_TOL)
     g = orc.backward(st, f(wc) / wc.numel(), f(wd) / wd.numel(), f(view.projection_matrix))
     tau = g["dL_dtau_sum"]
     assert hp.rel_err(f(view.cam_trans_delta.grad), tau[:3]) < GRAD_TOL
