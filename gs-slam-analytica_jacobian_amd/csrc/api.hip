@@ -92,8 +92,10 @@ int gsaj_forward_preprocess(int P, int D, int M, int W, int H, const float *mean
                             const float *colors_precomp, const float *opacities, const float *scales,
                             float scale_modifier, const float *rotations, const float *cov3D_precomp,
                             const float *viewmatrix, const float *projmatrix, const float *campos, float tanfovx,
-                            float tanfovy, int prefiltered, int *radii, void *geom_ws, void *stream) {
-  if (P <= 0 || W <= 0 || H <= 0 || !means3D || !opacities || !viewmatrix || !projmatrix || !geom_ws) {
+                            float tanfovy, int prefiltered, int *radii, int *n_touched, void *geom_ws, void *image_ws,
+                            void *stream) {
+  if (P <= 0 || W <= 0 || H <= 0 || !means3D || !opacities || !viewmatrix || !projmatrix || !geom_ws || !image_ws ||
+      !n_touched) {
     gsaj_set_error("gsaj_forward_preprocess: invalid argument (P=%d W=%d H=%d)", P, W, H);
     return GSAJ_ERR_INVALID_ARGUMENT;
   }
@@ -122,28 +124,36 @@ int gsaj_forward_preprocess(int P, int D, int M, int W, int H, const float *mean
   p.focal_x = W / (2.0f * tanfovx);
   p.prefiltered = prefiltered;
   p.grid_x = (W + TILE - 1) / TILE; p.grid_y = (H + TILE - 1) / TILE;
-  return launch_preprocess(p, radii ? radii : g.internal_radii, g, (hipStream_t)stream);
+  ImageWS im;
+  image_carve(align_base(image_ws), W, H, &im);
+  return launch_preprocess(p, radii ? radii : g.internal_radii, n_touched, g, im, (hipStream_t)stream);
 }
 
-int gsaj_forward_num_rendered(int P, const void *geom_ws, void *stream, int *num_rendered) {
-  if (P <= 0 || !geom_ws || !num_rendered) {
+int gsaj_forward_num_rendered(int W, int H, const void *image_ws, void *stream, int *num_rendered, int *max_tile_list) {
+  if (W <= 0 || H <= 0 || !image_ws || !num_rendered) {
     gsaj_set_error("gsaj_forward_num_rendered: invalid argument");
     return GSAJ_ERR_INVALID_ARGUMENT;
   }
-  GeomWS g;
-  geom_carve(align_base(const_cast<void *>(geom_ws)), (size_t)P, &g);
-  uint32_t host[2] = {0, 0};
-  GSAJ_HIP_CHECK(hipMemcpyAsync(host, g.counters, sizeof(host), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  ImageWS im;
+  image_carve(align_base(const_cast<void *>(image_ws)), W, H, &im);
+  uint32_t host[4] = {0, 0, 0, 0};
+  GSAJ_HIP_CHECK(hipMemcpyAsync(host, im.counters, sizeof(host), hipMemcpyDeviceToHost, (hipStream_t)stream));
   GSAJ_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
   *num_rendered = (int)host[0];
-  if (host[1] != 0) {
+  if (max_tile_list) *max_tile_list = (int)host[2];
+  if (host[1] == 1u) {
     gsaj_set_error("Point is filtered although prefiltered is set. This shouldn't happen!");
     return GSAJ_ERR_PREFILTERED_CULLED;
+  }
+  if (host[1] != 0u) {
+    gsaj_set_error("internal error: tile histogram total != instance total");
+    return GSAJ_ERR_HIP;
   }
   return GSAJ_OK;
 }
 
-int gsaj_forward_render(int P, int R, int W, int H, const float *bg, const float *colors_precomp, const int *radii,
+int gsaj_forward_render(int P, int R, int max_tile_list, int W, int H, const float *bg, const float *colors_precomp,
+                        const int *radii,
                         void *geom_ws, void *binning_ws, size_t binning_ws_bytes, void *image_ws, float *out_color,
                         float *out_depth, float *out_opacity, int *n_touched, void *stream) {
   if (P <= 0 || R < 0 || W <= 0 || H <= 0 || !bg || !geom_ws || !binning_ws || !image_ws || !out_color || !out_depth ||
@@ -167,10 +177,16 @@ int gsaj_forward_render(int P, int R, int W, int H, const float *bg, const float
   const int *rad = radii ? radii : g.internal_radii;
   const float *features = colors_precomp ? colors_precomp : g.rgb;
   int rc;
-  GSAJ_HIP_CHECK(hipMemsetAsync(n_touched, 0, sizeof(int) * (size_t)P, s));
-  if ((rc = launch_emit_keys(P, gx, gy, rad, g, b, s)) != GSAJ_OK) return rc;
-  if ((rc = launch_sort(R, 32 + (int)higher_msb((uint32_t)(gx * gy)), b, s)) != GSAJ_OK) return rc;
-  if ((rc = launch_ranges_and_records(P, R, gx, gy, rad, features, g, b, im, s)) != GSAJ_OK) return rc;
+  if (max_tile_list >= 0 && max_tile_list <= SORT_CAP) {
+    // fast path: per-tile lists sorted in LDS
+    if ((rc = launch_tile_binning(P, R, gx, gy, rad, features, g, b, im, s)) != GSAJ_OK) return rc;
+  } else {
+    // a tile list exceeds the LDS sort capacity (or the caller forces it with max_tile_list < 0):
+    // global radix sort of (tile << 32 | depth) keys, as the reference does
+    if ((rc = launch_emit_keys(P, gx, gy, rad, g, b, s)) != GSAJ_OK) return rc;
+    if ((rc = launch_sort(R, 32 + (int)higher_msb((uint32_t)(gx * gy)), b, s)) != GSAJ_OK) return rc;
+    if ((rc = launch_ranges_and_records(P, R, gx, gy, rad, features, g, b, im, s)) != GSAJ_OK) return rc;
+  }
   return launch_render_forward(W, H, gx, gy, bg, b, im, out_color, out_depth, out_opacity, n_touched, s);
 }
 
@@ -183,13 +199,13 @@ int gsaj_rasterize_forward(int P, int D, int M, const float *bg, int W, int H, c
                            void *image_ws, int *num_rendered_out, void *stream) {
   int rc = gsaj_forward_preprocess(P, D, M, W, H, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
                                    rotations, cov3D_precomp, viewmatrix, projmatrix, campos, tanfovx, tanfovy,
-                                   prefiltered, radii, geom_ws, stream);
+                                   prefiltered, radii, n_touched, geom_ws, image_ws, stream);
   if (rc != GSAJ_OK) return rc;
-  int R = 0;
-  rc = gsaj_forward_num_rendered(P, geom_ws, stream, &R);
+  int R = 0, max_tile = 0;
+  rc = gsaj_forward_num_rendered(W, H, image_ws, stream, &R, &max_tile);
   if (num_rendered_out) *num_rendered_out = R;
   if (rc != GSAJ_OK) return rc;
-  rc = gsaj_forward_render(P, R, W, H, bg, colors_precomp, radii, geom_ws, binning_ws, binning_ws_bytes, image_ws,
+  rc = gsaj_forward_render(P, R, max_tile, W, H, bg, colors_precomp, radii, geom_ws, binning_ws, binning_ws_bytes, image_ws,
                            out_color, out_depth, out_opacity, n_touched, stream);
   return rc == GSAJ_OK ? R : rc;
 }
@@ -221,20 +237,7 @@ int gsaj_rasterize_backward(int P, int D, int M, int R, const float *bg, int W, 
   BinWS b;
   bin_carve(align_base(binning_ws), (size_t)R, gsaj_sort_temp_bytes(R), &b);
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-  // zero-init of every accumulated / sparsely written output (rasterize_points.cu:175-185)
-  const size_t Pz = (size_t)P;
-  GSAJ_HIP_CHECK(hipMemsetAsync(dL_dmean2D, 0, sizeof(float) * 3 * Pz, s));
-  GSAJ_HIP_CHECK(hipMemsetAsync(dL_dconic, 0, sizeof(float) * 4 * Pz, s));
-  GSAJ_HIP_CHECK(hipMemsetAsync(dL_dopacity, 0, sizeof(float) * Pz, s));
-  GSAJ_HIP_CHECK(hipMemsetAsync(dL_dcolor, 0, sizeof(float) * 3 * Pz, s));
-  GSAJ_HIP_CHECK(hipMemsetAsync(dL_ddepth, 0, sizeof(float) * Pz, s));
-  GSAJ_HIP_CHECK(hipMemsetAsync(dL_dmean3D, 0, sizeof(float) * 3 * Pz, s));
-  GSAJ_HIP_CHECK(hipMemsetAsync(dL_dcov3D, 0, sizeof(float) * 6 * Pz, s));
-  if (dL_dsh && M > 0) GSAJ_HIP_CHECK(hipMemsetAsync(dL_dsh, 0, sizeof(float) * 3 * (size_t)M * Pz, s));
-  if (dL_dscale) GSAJ_HIP_CHECK(hipMemsetAsync(dL_dscale, 0, sizeof(float) * 3 * Pz, s));
-  if (dL_drot) GSAJ_HIP_CHECK(hipMemsetAsync(dL_drot, 0, sizeof(float) * 4 * Pz, s));
-  if (dL_dtau) GSAJ_HIP_CHECK(hipMemsetAsync(dL_dtau, 0, sizeof(float) * 6 * Pz, s));
-
+  // every output row is written by the kernels (zeros for culled Gaussians): no memsets
   int rc = launch_render_backward(R, W, H, gx, gy, bg, b, im, dL_dpix, dL_dpix_depth, s);
   if (rc != GSAJ_OK) return rc;
   BwdParams p;
@@ -251,7 +254,7 @@ int gsaj_rasterize_backward(int P, int D, int M, int R, const float *bg, int W, 
   p.dL_ddepth = dL_ddepth; p.dL_dmean3D = dL_dmean3D; p.dL_dcov3D = dL_dcov3D; p.dL_dsh = dL_dsh;
   p.dL_dscale = dL_dscale; p.dL_drot = dL_drot; p.dL_dtau = dL_dtau; p.dL_dtau_sum = dL_dtau_sum;
   (void)colors_precomp;
-  return launch_gaussian_backward(p, g, b, s);
+  return launch_gaussian_backward(p, g, b, im, s);
 }
 
 int gsaj_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix, uint8_t *present,

@@ -91,9 +91,11 @@ __device__ __forceinline__ float3 sh_backward(int deg, float3 pos, float3 campos
   return dnormvdv(dorig, ddir);
 }
 
-__global__ __launch_bounds__(PRE_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g, const uint32_t *__restrict__ inv_pos,
+__global__ __launch_bounds__(PRE_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g, uint32_t *__restrict__ counters,
+                                                            const uint32_t *__restrict__ inv_pos,
                                                             const float4 *__restrict__ inst_grad) {
   __shared__ float wsum[PRE_BLOCK / 64][6];
+  __shared__ uint32_t s_ticket;
   const int tid = threadIdx.x;
   const int idx = blockIdx.x * PRE_BLOCK + tid;
   float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -116,8 +118,9 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS 
     const float gop = s1.y;
     const float3 gcol = make_float3(s1.z, s1.w, s2.x);
     const float gz = s2.y;
-    p.dL_dmean2D[3 * (size_t)idx] = g2x; p.dL_dmean2D[3 * (size_t)idx + 1] = g2y;
-    p.dL_dconic[4 * (size_t)idx] = gcx; p.dL_dconic[4 * (size_t)idx + 1] = gcy; p.dL_dconic[4 * (size_t)idx + 3] = gcz;
+    p.dL_dmean2D[3 * (size_t)idx] = g2x; p.dL_dmean2D[3 * (size_t)idx + 1] = g2y; p.dL_dmean2D[3 * (size_t)idx + 2] = 0.f;
+    p.dL_dconic[4 * (size_t)idx] = gcx; p.dL_dconic[4 * (size_t)idx + 1] = gcy; p.dL_dconic[4 * (size_t)idx + 2] = 0.f;
+    p.dL_dconic[4 * (size_t)idx + 3] = gcz;
     p.dL_dopacity[idx] = gop;
     p.dL_dcolor[3 * (size_t)idx] = gcol.x; p.dL_dcolor[3 * (size_t)idx + 1] = gcol.y; p.dL_dcolor[3 * (size_t)idx + 2] = gcol.z;
     p.dL_ddepth[idx] = gz;
@@ -236,6 +239,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS 
                                        p.dL_dsh + (size_t)idx * p.M * 3);
       gm.x += dmean.x; gm.y += dmean.y; gm.z += dmean.z;
       tau[0] -= dmean.x; tau[1] -= dmean.y; tau[2] -= dmean.z;
+      for (int k = (p.D + 1) * (p.D + 1) * 3; k < p.M * 3; k++) p.dL_dsh[(size_t)idx * p.M * 3 + k] = 0.f;
     }
     p.dL_dmean3D[3 * (size_t)idx] = gm.x; p.dL_dmean3D[3 * (size_t)idx + 1] = gm.y; p.dL_dmean3D[3 * (size_t)idx + 2] = gm.z;
     // ---- 6. cov3D -> scale, rotation ----
@@ -274,6 +278,27 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS 
 #pragma unroll
       for (int k = 0; k < 6; k++) p.dL_dtau[6 * (size_t)idx + k] = tau[k];
     }
+  } else if (idx < p.P) {
+    // culled Gaussian: its rows are zero (the reference's binding memsets every output first)
+    const size_t i = (size_t)idx;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { p.dL_dmean2D[3 * i + k] = 0.f; p.dL_dcolor[3 * i + k] = 0.f; p.dL_dmean3D[3 * i + k] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < 4; k++) p.dL_dconic[4 * i + k] = 0.f;
+    p.dL_dopacity[i] = 0.f;
+    p.dL_ddepth[i] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 6; k++) p.dL_dcov3D[6 * i + k] = 0.f;
+    if (p.shs) for (int k = 0; k < p.M * 3; k++) p.dL_dsh[i * p.M * 3 + k] = 0.f;
+    if (p.scales) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) p.dL_dscale[3 * i + k] = 0.f;
+      reinterpret_cast<float4 *>(p.dL_drot)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (p.dL_dtau) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) p.dL_dtau[6 * i + k] = 0.f;
+    }
   }
   // ---- 7. workgroup partial of dL/dtau (fixed reduction tree) ----
 #pragma unroll
@@ -290,35 +315,47 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS 
     for (int w = 0; w < PRE_BLOCK / 64; w++) v += wsum[w][tid];
     g.tau_partials[(size_t)blockIdx.x * 8 + tid] = v;
   }
-}
-
-// Final fixed-order sum of the workgroup partials -> dL_dtau_sum[6] (fp64 accumulation).
-__global__ __launch_bounds__(256) void k_tau_finalize(int nblk, const float *__restrict__ partials, float *__restrict__ out) {
-  __shared__ double sh[256];
-  const int tid = threadIdx.x;
+  if (!p.dL_dtau_sum) return;
+  // ---- 8. the last workgroup to arrive sums the partials in workgroup order (fp64): deterministic,
+  // no extra launch (replaces torch.sum over [P,6], diff_gaussian_rasterization/__init__.py:162).
+  // Hand-off: plain stores -> vmcnt(0) -> barrier -> agent release -> ticket; the last arriver
+  // acquires before reading the other workgroups' partials (cdna_hip_programming.md G16).
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_ticket = __hip_atomic_fetch_add(&counters[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (s_ticket == gridDim.x - 1) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  __syncthreads();
+  if (s_ticket != gridDim.x - 1) return;
+  __shared__ double red[PRE_BLOCK];
+  const int nblk = (int)gridDim.x;
   for (int k = 0; k < 6; k++) {
     double v = 0.0;
-    for (int i = tid; i < nblk; i += 256) v += (double)partials[(size_t)i * 8 + k];
-    sh[tid] = v;
+    for (int i = tid; i < nblk; i += PRE_BLOCK)
+      v += (double)__hip_atomic_load(&g.tau_partials[(size_t)i * 8 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    red[tid] = v;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if (tid < o) sh[tid] += sh[tid + o];
+    for (int o = PRE_BLOCK / 2; o > 0; o >>= 1) {
+      if (tid < o) red[tid] += red[tid + o];
       __syncthreads();
     }
-    if (tid == 0) out[k] = (float)sh[0];
+    if (tid == 0) p.dL_dtau_sum[k] = (float)red[0];
     __syncthreads();
   }
+  if (tid == 0) counters[3] = 0u;  // ready for the next backward over this workspace
 }
 
-int launch_gaussian_backward(const BwdParams &p, const GeomWS &g, const BinWS &b, hipStream_t s) {
+int launch_gaussian_backward(const BwdParams &p, const GeomWS &g, const BinWS &b, const ImageWS &im, hipStream_t s) {
   const int nblk = (p.P + PRE_BLOCK - 1) / PRE_BLOCK;
   {
     GsajProfScope ps(ST_GAUSSIAN_BWD, s);
-    hipLaunchKernelGGL(k_gaussian_bwd, dim3(nblk), dim3(PRE_BLOCK), 0, s, p, g, b.inv_pos, b.inst_grad);
-  }
-  if (p.dL_dtau_sum) {
-    GsajProfScope ps(ST_TAU_FINALIZE, s);
-    hipLaunchKernelGGL(k_tau_finalize, dim3(1), dim3(256), 0, s, nblk, g.tau_partials, p.dL_dtau_sum);
+    hipLaunchKernelGGL(k_gaussian_bwd, dim3(nblk), dim3(PRE_BLOCK), 0, s, p, g, im.counters, b.inv_pos, b.inst_grad);
   }
   GSAJ_HIP_CHECK(hipGetLastError());
   return GSAJ_OK;

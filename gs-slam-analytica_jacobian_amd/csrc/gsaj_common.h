@@ -34,7 +34,6 @@ struct GeomWS {  // per-Gaussian state (reference: GeometryState, rasterizer_imp
   uint32_t *point_offsets;  // [P] inclusive scan of tiles_touched
   int *internal_radii;      // [P]
   uint32_t *block_sums;     // [nblk] per-workgroup totals, then exclusive offsets
-  uint32_t *counters;       // [0] num_rendered, [1] error flag
   float *tau_partials;      // [nblk*8] per-workgroup dL/dtau partial sums
 };
 
@@ -57,15 +56,24 @@ static inline __host__ __device__ size_t geom_carve(char *base, size_t P, GeomWS
   CARVE(point_offsets, uint32_t, P);
   CARVE(internal_radii, int, P);
   CARVE(block_sums, uint32_t, nblk);
-  CARVE(counters, uint32_t, 64);
   CARVE(tau_partials, float, nblk * 8);
   return off;
 }
 
+#define TILE_REP 1        // replicas of each tile's instance counter (1: contention is removed by LDS aggregation)
+#define LDS_TILES_MAX 8192  // images with more tiles than this bin with direct global atomics
+#define SORT_CAP 4096     // largest tile list the in-LDS tile sort handles; longer lists -> global radix fallback
+#define N_COUNTERS 64     // frame counters: [0] num_rendered [1] error flag [2] longest tile list [3] tau ticket
+
 struct ImageWS {  // reference: ImageState, rasterizer_impl.h:46-53
-  float *final_T;       // [H*W]
-  uint32_t *n_contrib;  // [H*W]
-  uint2 *ranges;        // [tiles]
+  float *final_T;         // [H*W]
+  uint32_t *n_contrib;    // [H*W]
+  uint2 *ranges;          // [tiles]
+  uint32_t *counters;     // [N_COUNTERS]            -+
+  uint32_t *tile_count;   // [tiles*TILE_REP]         | zeroed by ONE memset per forward
+  uint32_t *tile_cursor;  // [tiles*TILE_REP]        -+
+  uint32_t *tile_offset;  // [tiles*TILE_REP + 1] exclusive scan of tile_count (tile-major)
+  size_t zero_bytes;      // bytes from counters to the end of tile_cursor
 };
 
 static inline __host__ __device__ size_t image_carve(char *base, int W, int H, ImageWS *s) {
@@ -76,11 +84,17 @@ static inline __host__ __device__ size_t image_carve(char *base, int W, int H, I
   CARVE(final_T, float, N);
   CARVE(n_contrib, uint32_t, N);
   CARVE(ranges, uint2, tiles);
+  const size_t z0 = off;
+  CARVE(counters, uint32_t, N_COUNTERS);
+  CARVE(tile_count, uint32_t, tiles * TILE_REP);
+  CARVE(tile_cursor, uint32_t, tiles * TILE_REP);
+  if (g) g->zero_bytes = off - z0;
+  CARVE(tile_offset, uint32_t, tiles * TILE_REP + 1);
   return off;
 }
 
 struct BinWS {  // reference: BinningState, rasterizer_impl.h:55-66
-  uint64_t *keys_unsorted;  // [R]
+  uint64_t *keys_unsorted;  // [R] fast path: (depth bits << 32 | id) grouped by tile; fallback: (tile << 32 | depth bits)
   uint64_t *keys;           // [R]
   uint32_t *vals_unsorted;  // [R]
   uint32_t *point_list;     // [R] sorted Gaussian ids
@@ -123,7 +137,7 @@ void gsaj_set_error(const char *fmt, ...);
 // ---- optional per-stage timing with HIP events on the launch stream (api.hip) --------------
 enum GsajStage {
   ST_PREPROCESS = 0, ST_SCAN, ST_EMIT_KEYS, ST_SORT, ST_RANGES_RECORDS, ST_RENDER_FWD, ST_RENDER_BWD, ST_GAUSSIAN_BWD,
-  ST_TAU_FINALIZE, ST_DENSE_BWD, ST_DENSE_REDUCE, ST_COUNT
+  ST_TAU_FINALIZE, ST_DENSE_BWD, ST_DENSE_REDUCE, ST_SCATTER, ST_TILE_SORT, ST_COUNT
 };
 void gsaj_prof_mark(int stage, int is_stop, hipStream_t s);
 struct GsajProfScope {
@@ -143,7 +157,9 @@ struct FwdParams {
   int grid_x, grid_y;
 };
 
-int launch_preprocess(const FwdParams &p, int *radii, const GeomWS &g, hipStream_t s);
+int launch_preprocess(const FwdParams &p, int *radii, int *n_touched, const GeomWS &g, const ImageWS &im, hipStream_t s);
+int launch_tile_binning(int P, int R, int grid_x, int grid_y, const int *radii, const float *features, const GeomWS &g,
+                        const BinWS &b, const ImageWS &im, hipStream_t s);
 int launch_emit_keys(int P, int grid_x, int grid_y, const int *radii, const GeomWS &g, const BinWS &b, hipStream_t s);
 int launch_sort(int R, int end_bit, const BinWS &b, hipStream_t s);
 int launch_ranges_and_records(int P, int R, int grid_x, int grid_y, const int *radii, const float *features,
@@ -162,7 +178,7 @@ struct BwdParams {
   float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_ddepth, *dL_dmean3D, *dL_dcov3D, *dL_dsh, *dL_dscale,
       *dL_drot, *dL_dtau, *dL_dtau_sum;
 };
-int launch_gaussian_backward(const BwdParams &p, const GeomWS &g, const BinWS &b, hipStream_t s);
+int launch_gaussian_backward(const BwdParams &p, const GeomWS &g, const BinWS &b, const ImageWS &im, hipStream_t s);
 int launch_mark_visible(int P, const float *means3D, const float *viewmatrix, uint8_t *present, hipStream_t s);
 
 // ---- small device helpers -------------------------------------------------------------------

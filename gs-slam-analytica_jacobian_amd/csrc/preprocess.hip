@@ -102,10 +102,18 @@ __device__ __forceinline__ float3 sh_to_rgb(int deg, float3 pos, float3 campos, 
   return make_float3(out[0], out[1], out[2]);
 }
 
-__global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__restrict__ radii, GeomWS g) {
+__global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__restrict__ radii, int *__restrict__ n_touched,
+                                                         GeomWS g, ImageWS im) {
   __shared__ uint32_t scan[PRE_BLOCK];
+  extern __shared__ uint32_t hist[];  // [tiles] workgroup-local tile histogram (when tiles <= LDS_TILES_MAX)
   const int tid = threadIdx.x;
   const int idx = blockIdx.x * PRE_BLOCK + tid;
+  const int tiles = p.grid_x * p.grid_y;
+  const bool use_lds = tiles <= LDS_TILES_MAX;
+  if (use_lds) {
+    for (int t = tid; t < tiles; t += PRE_BLOCK) hist[t] = 0u;
+    __syncthreads();
+  }
   uint32_t touched = 0;
   if (idx < p.P) {
     int my_radius_i = 0;
@@ -118,7 +126,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__re
     const float3 p_orig = ld3(p.means3D, idx);
     const float3 p_view = xform4x3(p.viewmatrix, p_orig);
     if (p_view.z <= 0.2f) {
-      if (p.prefiltered) g.counters[1] = 1u;  // the reference traps here (auxiliary.h:156-160)
+      if (p.prefiltered) im.counters[1] = 1u;  // the reference traps here (auxiliary.h:156-160)
     } else {
       const float4 p_hom = xform4x4(p.projmatrix, p_orig);
       const float p_w = 1.0f / (p_hom.w + 0.0000001f);
@@ -155,10 +163,18 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__re
           xy = pim;
           con_o = make_float4(conic.x, conic.y, conic.z, p.opacities[idx]);
           touched = (uint32_t)area;
+          // per-tile instance histogram: LDS atomics here, one coalesced global flush per workgroup
+          // (a scattered global atomic wave-instruction costs ~17x a contiguous one)
+          for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++) {
+              if (use_lds) atomicAdd(&hist[y * p.grid_x + x], 1u);
+              else atomicAdd(&im.tile_count[y * p.grid_x + x], 1u);
+            }
         }
       }
     }
     radii[idx] = my_radius_i;
+    n_touched[idx] = 0;
     g.depths[idx] = depth;
     g.means2D[idx] = xy;
     g.conic_opacity[idx] = con_o;
@@ -175,6 +191,11 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__re
   // block-local inclusive scan of tiles_touched (Hillis-Steele over 256 lanes)
   scan[tid] = touched;
   __syncthreads();
+  if (use_lds)
+    for (int t = tid; t < tiles; t += PRE_BLOCK) {
+      const uint32_t c = hist[t];
+      if (c) atomicAdd(&im.tile_count[t], c);
+    }
 #pragma unroll
   for (int o = 1; o < PRE_BLOCK; o <<= 1) {
     uint32_t v = (tid >= o) ? scan[tid - o] : 0u;
@@ -186,33 +207,188 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__re
   if (tid == PRE_BLOCK - 1) g.block_sums[blockIdx.x] = scan[tid];
 }
 
-// Exclusive scan of the per-workgroup totals (one workgroup; nblk = P/256 is small) and the
-// grand total R -> counters[0].
-__global__ __launch_bounds__(1024) void k_scan_blocks(int nblk, uint32_t *__restrict__ block_sums,
-                                                      uint32_t *__restrict__ counters) {
-  __shared__ uint32_t sh[1024];
-  __shared__ uint32_t carry;
-  const int tid = threadIdx.x;
-  if (tid == 0) carry = 0;
+// Single-workgroup exclusive scan of n items: each lane sums a contiguous run, the 1024 run totals
+// are scanned with wave shuffles + one LDS hop, then each lane rewrites its run.  Returns the total.
+__device__ uint32_t block_exclusive_scan(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, int n,
+                                         uint32_t *__restrict__ run_max) {
+  __shared__ uint32_t wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (n + 1023) / 1024;
+  const int b0 = min(n, tid * per), b1 = min(n, b0 + per);
+  uint32_t s = 0;
+  for (int i = b0; i < b1; i++) s += in[i];
+  uint32_t incl = s;  // inclusive scan of s over the 1024 lanes
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t v = __shfl_up((int)incl, o);
+    if (lane >= o) incl += v;
+  }
+  if (lane == 63) wsum[wave] = incl;
   __syncthreads();
-  for (int base = 0; base < nblk; base += 1024) {
-    const int i = base + tid;
-    const uint32_t v = (i < nblk) ? block_sums[i] : 0u;
-    sh[tid] = v;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-      uint32_t a = (tid >= o) ? sh[tid - o] : 0u;
-      __syncthreads();
-      sh[tid] += a;
-      __syncthreads();
-    }
-    const uint32_t c = carry;
-    if (i < nblk) block_sums[i] = c + sh[tid] - v;  // exclusive
-    __syncthreads();
-    if (tid == 1023) carry = c + sh[1023];
+  uint32_t woff = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 16; w++) {
+    const uint32_t v = wsum[w];
+    if (w < wave) woff += v;
+    total += v;
+  }
+  uint32_t run = woff + incl - s;
+  (void)run_max;
+  for (int i = b0; i < b1; i++) {
+    const uint32_t v = in[i];
+    out[i] = run;
+    run += v;
+  }
+  __syncthreads();
+  return total;
+}
+
+// One launch, one workgroup: (1) exclusive offsets of the per-workgroup Gaussian totals and the
+// grand total R; (2) exclusive offsets of the replicated per-tile histogram in tile-major order, so
+// a tile's list is the contiguous union of its replicas' segments; (3) the longest tile list.
+__global__ __launch_bounds__(1024) void k_scan(int nblk, int tiles, uint32_t *__restrict__ block_sums, ImageWS im) {
+  __shared__ uint32_t smax[16];
+  const int tid = threadIdx.x;
+  const uint32_t R = block_exclusive_scan(block_sums, block_sums, nblk, nullptr);
+  uint32_t mx = 0;
+  for (int t = tid; t < tiles; t += 1024) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int r = 0; r < TILE_REP; r++) c += im.tile_count[t * TILE_REP + r];
+    mx = max(mx, c);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+  if ((tid & 63) == 0) smax[tid >> 6] = mx;
+  const uint32_t R2 = block_exclusive_scan(im.tile_count, im.tile_offset, tiles * TILE_REP, nullptr);
+  if (tid == 0) {
+    uint32_t m = 0;
+    for (int w = 0; w < 16; w++) m = max(m, smax[w]);
+    im.tile_offset[tiles * TILE_REP] = R2;
+    im.counters[0] = R;
+    im.counters[2] = m;
+    if (R2 != R) im.counters[1] = 2u;  // cannot happen; guards the invariant sum(tile lists) == sum(tiles_touched)
+  }
+}
+
+// Fast path: every Gaussian drops (depth bits << 32 | id) into a free slot of each touched tile's
+// list segment.  A workgroup first counts its instances per tile in LDS, reserves one contiguous
+// slot range per tile with a single coalesced pass of returning global atomics, then hands out the
+// slots with LDS atomics.  Slot order inside a tile is arbitrary; the tile sort orders by
+// (depth, id), a total order, so the final lists are deterministic.
+// Also turns point_offsets into the global inclusive scan (emission slots for the backward).
+__global__ __launch_bounds__(PRE_BLOCK) void k_scatter_instances(int P, int gx, int gy, const int *__restrict__ radii,
+                                                                 GeomWS g, ImageWS im, uint64_t *__restrict__ inst_key) {
+  extern __shared__ uint32_t lds[];  // [2*tiles]: count -> reserved base, fill cursor
+  const int tid = threadIdx.x;
+  const int idx = blockIdx.x * PRE_BLOCK + tid;
+  const int tiles = gx * gy;
+  const bool use_lds = tiles <= LDS_TILES_MAX;
+  uint32_t *cnt = lds, *fill = lds + tiles;
+  if (use_lds) {
+    for (int t = tid; t < 2 * tiles; t += PRE_BLOCK) lds[t] = 0u;
     __syncthreads();
   }
-  if (tid == 0) counters[0] = carry;
+  int r = 0, x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+  uint64_t key = 0;
+  if (idx < P) {
+    g.point_offsets[idx] = g.block_sums[blockIdx.x] + g.point_offsets[idx];
+    r = radii[idx];
+    if (r > 0) {
+      const float2 xy = g.means2D[idx];
+      tile_rect(xy.x, xy.y, r, gx, gy, x0, y0, x1, y1);
+      key = ((uint64_t)__float_as_uint(g.depths[idx]) << 32) | (uint32_t)idx;
+    }
+  }
+  if (!use_lds) {
+    for (int y = y0; y < y1; y++)
+      for (int x = x0; x < x1; x++) {
+        const int c = y * gx + x;
+        inst_key[im.tile_offset[c] + atomicAdd(&im.tile_cursor[c], 1u)] = key;
+      }
+    return;
+  }
+  for (int y = y0; y < y1; y++)
+    for (int x = x0; x < x1; x++) atomicAdd(&cnt[y * gx + x], 1u);
+  __syncthreads();
+  for (int t = tid; t < tiles; t += PRE_BLOCK) {
+    const uint32_t c = cnt[t];
+    if (c) cnt[t] = im.tile_offset[t] + atomicAdd(&im.tile_cursor[t], c);  // this workgroup's slot range in tile t
+  }
+  __syncthreads();
+  for (int y = y0; y < y1; y++)
+    for (int x = x0; x < x1; x++) {
+      const int c = y * gx + x;
+      inst_key[cnt[c] + atomicAdd(&fill[c], 1u)] = key;
+    }
+}
+
+// One workgroup per tile: bitonic sort of the tile's (depth, id) keys in LDS, then the sorted
+// Gaussian ids, the 48-byte instance records, the emission-slot -> sorted-position map and the
+// tile's [start, end) range are written in one pass.
+__global__ __launch_bounds__(256) void k_tile_sort_records(int gx, int gy, const int *__restrict__ radii,
+                                                           const float *__restrict__ features, GeomWS g, ImageWS im,
+                                                           const uint64_t *__restrict__ inst_key,
+                                                           uint32_t *__restrict__ point_list,
+                                                           float4 *__restrict__ records, uint32_t *__restrict__ inv_pos) {
+  __shared__ uint64_t keys[SORT_CAP];
+  const int tid = threadIdx.x, tile = blockIdx.x;
+  const uint32_t beg = im.tile_offset[tile * TILE_REP], end = im.tile_offset[(tile + 1) * TILE_REP];
+  const int n = (int)(end - beg);
+  if (tid == 0) im.ranges[tile] = n > 0 ? make_uint2(beg, end) : make_uint2(0u, 0u);
+  if (n == 0) return;
+  int m = 2;
+  while (m < n) m <<= 1;
+  for (int i = tid; i < m; i += 256) keys[i] = i < n ? inst_key[beg + i] : ~0ull;
+  __syncthreads();
+  // Bitonic network.  Comparators with stride j <= 64 pair keys inside one aligned 128-key chunk, so
+  // a wave that owns whole chunks runs ALL such consecutive stages without a workgroup barrier
+  // (LDS operations of one wave complete in order); only strides >= 128 need __syncthreads.
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int k = 2; k <= m; k <<= 1) {
+    int j = k >> 1;
+    for (; j >= 128; j >>= 1) {
+      for (int i = tid; i < (m >> 1); i += 256) {
+        const int l = ((i & ~(j - 1)) << 1) | (i & (j - 1)), r = l + j;
+        const uint64_t a = keys[l], b = keys[r];
+        if ((a > b) == ((l & k) == 0)) {
+          keys[l] = b;
+          keys[r] = a;
+        }
+      }
+      __syncthreads();
+    }
+    for (int chunk = wave; chunk * 128 < m; chunk += 4) {  // 64 comparators per 128-key chunk
+      for (int jj = j; jj > 0; jj >>= 1) {
+        const int i = chunk * 64 + lane;
+        if (i < (m >> 1)) {
+          const int l = ((i & ~(jj - 1)) << 1) | (i & (jj - 1)), r = l + jj;
+          const uint64_t a = keys[l], b = keys[r];
+          if ((a > b) == ((l & k) == 0)) {
+            keys[l] = b;
+            keys[r] = a;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const int ty = tile / gx, tx = tile - ty * gx;
+  for (int i = tid; i < n; i += 256) {
+    const uint64_t key = keys[i];
+    const uint32_t id = (uint32_t)key;
+    const uint32_t k = beg + (uint32_t)i;
+    point_list[k] = id;
+    const float2 xy = g.means2D[id];
+    records[(size_t)k * REC_F4 + 0] = make_float4(xy.x, xy.y, __uint_as_float((uint32_t)(key >> 32)), __uint_as_float(id));
+    records[(size_t)k * REC_F4 + 1] = g.conic_opacity[id];
+    records[(size_t)k * REC_F4 + 2] =
+        make_float4(features[3 * (size_t)id], features[3 * (size_t)id + 1], features[3 * (size_t)id + 2], 0.f);
+    int x0, y0, x1, y1;
+    tile_rect(xy.x, xy.y, radii[id], gx, gy, x0, y0, x1, y1);
+    const uint32_t first = g.point_offsets[id] - g.tiles_touched[id];
+    inv_pos[first + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0))] = k;
+  }
 }
 
 // One (tile, depth) key + Gaussian id per touched tile, written at the Gaussian's slot range.
@@ -247,16 +423,38 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_mark_visible(int P, const float *
   present[idx] = pv.z > 0.2f;
 }
 
-int launch_preprocess(const FwdParams &p, int *radii, const GeomWS &g, hipStream_t s) {
+int launch_preprocess(const FwdParams &p, int *radii, int *n_touched, const GeomWS &g, const ImageWS &im, hipStream_t s) {
   const int nblk = (p.P + PRE_BLOCK - 1) / PRE_BLOCK;
-  GSAJ_HIP_CHECK(hipMemsetAsync(g.counters, 0, 64 * sizeof(uint32_t), s));
+  GSAJ_HIP_CHECK(hipMemsetAsync(im.counters, 0, im.zero_bytes, s));  // the only memset of a forward
   {
     GsajProfScope ps(ST_PREPROCESS, s);
-    hipLaunchKernelGGL(k_preprocess, dim3(nblk), dim3(PRE_BLOCK), 0, s, p, radii, g);
+    const int tiles = p.grid_x * p.grid_y;
+    const size_t lds = tiles <= LDS_TILES_MAX ? sizeof(uint32_t) * (size_t)tiles : 0;
+    hipLaunchKernelGGL(k_preprocess, dim3(nblk), dim3(PRE_BLOCK), lds, s, p, radii, n_touched, g, im);
   }
   {
     GsajProfScope ps(ST_SCAN, s);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, nblk, g.block_sums, g.counters);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, nblk, p.grid_x * p.grid_y, g.block_sums, im);
+  }
+  GSAJ_HIP_CHECK(hipGetLastError());
+  return GSAJ_OK;
+}
+
+int launch_tile_binning(int P, int R, int grid_x, int grid_y, const int *radii, const float *features, const GeomWS &g,
+                        const BinWS &b, const ImageWS &im, hipStream_t s) {
+  (void)R;
+  const int nblk = (P + PRE_BLOCK - 1) / PRE_BLOCK;
+  {
+    GsajProfScope ps(ST_SCATTER, s);
+    const int tiles = grid_x * grid_y;
+    const size_t lds = tiles <= LDS_TILES_MAX ? 2 * sizeof(uint32_t) * (size_t)tiles : 0;
+    hipLaunchKernelGGL(k_scatter_instances, dim3(nblk), dim3(PRE_BLOCK), lds, s, P, grid_x, grid_y, radii, g, im,
+                       b.keys_unsorted);
+  }
+  {
+    GsajProfScope ps(ST_TILE_SORT, s);
+    hipLaunchKernelGGL(k_tile_sort_records, dim3(grid_x * grid_y), dim3(256), 0, s, grid_x, grid_y, radii, features, g, im,
+                       b.keys_unsorted, b.point_list, b.records, b.inv_pos);
   }
   GSAJ_HIP_CHECK(hipGetLastError());
   return GSAJ_OK;

@@ -65,9 +65,11 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int gx, const 
   const uint32_t bmax = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
 
   float accC0 = 0.f, accC1 = 0.f, accC2 = 0.f, accD = 0.f;  // accum_rec, accum_rec_depth
-  float lastC0 = 0.f, lastC1 = 0.f, lastC2 = 0.f, lastD = 0.f, last_alpha = 0.f;
 
-  uint32_t hi = range.x + bmax;  // exclusive sorted position; rows [hi, range.y) stay zero
+  uint32_t hi = range.x + bmax;  // exclusive sorted position
+  // rows [hi, range.y) were never reached by any pixel of the tile: their partials are zero
+  for (uint32_t k = hi * REC_F4 + tid; k < range.y * REC_F4; k += 256) inst_grad[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+
   while (hi > range.x) {
     const uint32_t lo = (hi - range.x > BWD_ROUND) ? hi - BWD_ROUND : range.x;
     const int n = (int)(hi - lo);
@@ -92,46 +94,42 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int gx, const 
         const float4 r1 = rec[j * REC_F4 + 1];
         const float dx = r0.x - pxf, dy = r0.y - pyf;
         const float power = -0.5f * (r1.x * dx * dx + r1.z * dy * dy) - r1.y * dx * dy;
-        const float G = __expf(power);
-        const float alpha = fminf(0.99f, r1.w * G);
-        const bool valid = idx < last && power <= 0.0f && alpha >= (1.0f / 255.0f);
-        if (__ballot(valid) == 0ull) continue;
+        const float G0 = __expf(power);
+        const float alpha0 = fminf(0.99f, r1.w * G0);
+        const bool valid = idx < last && power <= 0.0f && alpha0 >= (1.0f / 255.0f);
+        if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue;
         const float4 r2 = rec[j * REC_F4 + 2];
-
+        // A lane that skips this entry runs the same arithmetic with alpha = G = 0: T, accum_rec and
+        // every partial then come out unchanged / zero, so two selects replace ~20 predicated updates.
+        const float alpha = valid ? alpha0 : 0.f;
+        const float G = valid ? G0 : 0.f;
         const float inv1ma = __builtin_amdgcn_rcpf(1.f - alpha);
-        const float Tn = T * inv1ma;
-        const float dchannel = alpha * Tn;
-        const float one_m_la = 1.f - last_alpha;
-        const float aC0 = last_alpha * lastC0 + one_m_la * accC0;
-        const float aC1 = last_alpha * lastC1 + one_m_la * accC1;
-        const float aC2 = last_alpha * lastC2 + one_m_la * accC2;
-        const float aD = last_alpha * lastD + one_m_la * accD;
-        float dL_dalpha = (r2.x - aC0) * gC0 + (r2.y - aC1) * gC1 + (r2.z - aC2) * gC2 + (r0.z - aD) * gD;
-        dL_dalpha *= Tn;
-        dL_dalpha += (-T_final * inv1ma) * bg_dot;
+        T = T * inv1ma;  // T <- T / (1 - alpha)
+        const float dchannel = alpha * T;
+        float dL_dalpha = (r2.x - accC0) * gC0 + (r2.y - accC1) * gC1 + (r2.z - accC2) * gC2 + (r0.z - accD) * gD;
+        dL_dalpha = dL_dalpha * T - (T_final * inv1ma) * bg_dot;
+        // accum_rec for the next (nearer) entry: alpha c + (1 - alpha) accum_rec  (backward.cu:799,811,
+        // applied here instead of lazily at the top of the next iteration -- same arithmetic)
+        const float oma = 1.f - alpha;
+        accC0 = alpha * r2.x + oma * accC0;
+        accC1 = alpha * r2.y + oma * accC1;
+        accC2 = alpha * r2.z + oma * accC2;
+        accD = alpha * r0.z + oma * accD;
         const float dL_dG = r1.w * dL_dalpha;
         const float gdx = G * dx, gdy = G * dy;
         const float dG_ddelx = -gdx * r1.x - gdy * r1.y;
         const float dG_ddely = -gdy * r1.z - gdx * r1.y;
-
         float v[10];
-        v[0] = valid ? dL_dG * dG_ddelx * ddelx_dx : 0.f;
-        v[1] = valid ? dL_dG * dG_ddely * ddely_dy : 0.f;
-        v[2] = valid ? -0.5f * gdx * dx * dL_dG : 0.f;
-        v[3] = valid ? -0.5f * gdx * dy * dL_dG : 0.f;
-        v[4] = valid ? -0.5f * gdy * dy * dL_dG : 0.f;
-        v[5] = valid ? G * dL_dalpha : 0.f;
-        v[6] = valid ? dchannel * gC0 : 0.f;
-        v[7] = valid ? dchannel * gC1 : 0.f;
-        v[8] = valid ? dchannel * gC2 : 0.f;
-        v[9] = valid ? dchannel * gD : 0.f;
-        if (valid) {
-          T = Tn;
-          accC0 = aC0; accC1 = aC1; accC2 = aC2; accD = aD;
-          lastC0 = r2.x; lastC1 = r2.y; lastC2 = r2.z; lastD = r0.z;
-          last_alpha = alpha;
-        }
-
+        v[0] = dL_dG * dG_ddelx * ddelx_dx;
+        v[1] = dL_dG * dG_ddely * ddely_dy;
+        v[2] = -0.5f * gdx * dx * dL_dG;
+        v[3] = -0.5f * gdx * dy * dL_dG;
+        v[4] = -0.5f * gdy * dy * dL_dG;
+        v[5] = G * dL_dalpha;
+        v[6] = dchannel * gC0;
+        v[7] = dchannel * gC1;
+        v[8] = dchannel * gC2;
+        v[9] = dchannel * gD;
         // ---- wave reduction of the 10 partials (registers only), totals -> this wave's LDS slot ----
         float x0, x1, x2;
         reduce10(v, x0, x1, x2);
@@ -163,7 +161,6 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int gx, const 
 int launch_render_backward(int R, int W, int H, int grid_x, int grid_y, const float *bg, const BinWS &b,
                            const ImageWS &im, const float *dL_dpix, const float *dL_dpix_depth, hipStream_t s) {
   if (R <= 0) return GSAJ_OK;
-  GSAJ_HIP_CHECK(hipMemsetAsync(b.inst_grad, 0, sizeof(float4) * REC_F4 * (size_t)R, s));
   {
     GsajProfScope ps(ST_RENDER_BWD, s);
     hipLaunchKernelGGL(k_render_bwd, dim3(grid_x * grid_y), dim3(256), 0, s, W, H, grid_x, im.ranges, b.records, bg,

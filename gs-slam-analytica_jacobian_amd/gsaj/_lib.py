@@ -24,9 +24,9 @@ SIGNATURES = {
     "gsaj_geom_workspace_bytes": (c_size_t, [c_int]),
     "gsaj_image_workspace_bytes": (c_size_t, [c_int, c_int]),
     "gsaj_binning_workspace_bytes": (c_size_t, [c_int]),
-    "gsaj_forward_preprocess": (c_int, [c_int] * 5 + [P, P, P, P, P, c_float, P, P, P, P, P, c_float, c_float, c_int, P, P, P]),
-    "gsaj_forward_num_rendered": (c_int, [c_int, P, P, ctypes.POINTER(c_int)]),
-    "gsaj_forward_render": (c_int, [c_int] * 4 + [P, P, P, P, P, c_size_t, P, P, P, P, P, P]),
+    "gsaj_forward_preprocess": (c_int, [c_int] * 5 + [P, P, P, P, P, c_float, P, P, P, P, P, c_float, c_float, c_int, P, P, P, P, P]),
+    "gsaj_forward_num_rendered": (c_int, [c_int, c_int, P, P, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "gsaj_forward_render": (c_int, [c_int] * 5 + [P, P, P, P, P, c_size_t, P, P, P, P, P, P]),
     "gsaj_rasterize_forward": (c_int, [c_int, c_int, c_int, P, c_int, c_int, P, P, P, P, P, c_float, P, P, P, P, P,
                                        c_float, c_float, c_int, P, P, P, P, P, P, P, c_size_t, P,
                                        ctypes.POINTER(c_int), P]),
@@ -63,6 +63,10 @@ def load():
         raise ImportError(
             "libgsaj_hip.so is missing (%s). Build the HIP extension first: "
             "`python __graft_entry__.py` or `make -C %s`. There is no CPU fallback." % (LIB_PATH, CSRC))
+    # PyTorch supplies device memory and streams, so ITS HIP runtime must be the one the process
+    # initialises: import it before dlopen()ing the kernels (two runtimes in one process fail with
+    # "no ROCm-capable device is detected").
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly

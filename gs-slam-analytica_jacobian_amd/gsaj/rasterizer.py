@@ -12,6 +12,7 @@ import torch
 from . import _lib
 
 _F32 = torch.float32
+FORCE_GLOBAL_SORT = False  # tests flip this to exercise the global radix-sort binning path
 
 
 def _ptr(t):
@@ -83,15 +84,16 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         _lib.check(lib.gsaj_forward_preprocess(
             P, int(degree), M, W, H, _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales),
             float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix),
-            _ptr(campos), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), radii.data_ptr(), geom.data_ptr(),
-            st), "gsaj_forward_preprocess")
-        R = ctypes.c_int(0)
-        _lib.check(lib.gsaj_forward_num_rendered(P, geom.data_ptr(), st, ctypes.byref(R)), "gsaj_forward_num_rendered")
+            _ptr(campos), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), radii.data_ptr(),
+            n_touched.data_ptr(), geom.data_ptr(), img.data_ptr(), st), "gsaj_forward_preprocess")
+        R, mt = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(lib.gsaj_forward_num_rendered(W, H, img.data_ptr(), st, ctypes.byref(R), ctypes.byref(mt)),
+                   "gsaj_forward_num_rendered")
         R = R.value
         nbytes = lib.gsaj_binning_workspace_bytes(R)
         binning = torch.empty(nbytes, **byte)
         _lib.check(lib.gsaj_forward_render(
-            P, R, W, H, _ptr(background), _ptr(colors), radii.data_ptr(), geom.data_ptr(), binning.data_ptr(), nbytes,
+            P, R, -1 if FORCE_GLOBAL_SORT else mt.value, W, H, _ptr(background), _ptr(colors), radii.data_ptr(), geom.data_ptr(), binning.data_ptr(), nbytes,
             img.data_ptr(), out_color.data_ptr(), out_depth.data_ptr(), out_opacity.data_ptr(), n_touched.data_ptr(),
             st), "gsaj_forward_render")
         if debug:
@@ -206,7 +208,7 @@ def debug_export(P, R, W, H, geomBuffer, binningBuffer, imageBuffer):
 
 
 STAGE_NAMES = ("preprocess,scan_blocks,emit_keys,sort,ranges_records,render_fwd,render_bwd,gaussian_bwd,tau_finalize,"
-               "dense_bwd,dense_reduce").split(",")
+               "dense_bwd,dense_reduce,scatter_instances,tile_sort_records").split(",")
 
 
 class profile_stages:
@@ -275,14 +277,14 @@ class FrameContext:
             self.P, int(sh_degree), self.M, self.W, self.H, _ptr(means3D), _ptr(shs), _ptr(colors_precomp),
             _ptr(opacities), _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix),
             _ptr(projmatrix), _ptr(campos), float(tanfovx), float(tanfovy), 0, self.radii.data_ptr(),
-            self.geom.data_ptr(), st), "gsaj_forward_preprocess")
-        R = ctypes.c_int(0)
-        _lib.check(lib.gsaj_forward_num_rendered(self.P, self.geom.data_ptr(), st, ctypes.byref(R)),
+            self.n_touched.data_ptr(), self.geom.data_ptr(), self.img.data_ptr(), st), "gsaj_forward_preprocess")
+        R, mt = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(lib.gsaj_forward_num_rendered(self.W, self.H, self.img.data_ptr(), st, ctypes.byref(R), ctypes.byref(mt)),
                    "gsaj_forward_num_rendered")
-        self.R = R.value
+        self.R, self.max_tile_list = R.value, mt.value
         self._ensure_binning(self.R)
         _lib.check(lib.gsaj_forward_render(
-            self.P, self.R, self.W, self.H, _ptr(bg), _ptr(colors_precomp), self.radii.data_ptr(), self.geom.data_ptr(),
+            self.P, self.R, -1 if FORCE_GLOBAL_SORT else self.max_tile_list, self.W, self.H, _ptr(bg), _ptr(colors_precomp), self.radii.data_ptr(), self.geom.data_ptr(),
             self.binning.data_ptr(), self.binning.numel(), self.img.data_ptr(), self.color.data_ptr(),
             self.depth.data_ptr(), self.opacity.data_ptr(), self.n_touched.data_ptr(), st), "gsaj_forward_render")
         return self.R

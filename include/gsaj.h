@@ -31,8 +31,8 @@
  *   - return value: >= 0 on success (gsaj_rasterize_forward returns num_rendered),
  *     a negative GSAJ_ERR_* on failure; gsaj_last_error() describes the last failure of
  *     the calling thread.
- *   - outputs that kernels accumulate into (n_touched, every dL_d*) are zeroed by the
- *     library, as the reference's binding does (rasterize_points.cu:84-88,175-185).
+ *   - the caller need not zero anything: every output row is written by the kernels (zeros for
+ *     culled Gaussians), where the reference's binding zero-fills first (rasterize_points.cu:84-88,175-185).
  */
 #ifndef GSAJ_H_INCLUDED
 #define GSAJ_H_INCLUDED
@@ -71,13 +71,17 @@ int gsaj_forward_preprocess(int P, int D, int M, int W, int H,
                             const float *rotations /*dev [P,4] or NULL*/, const float *cov3D_precomp /*dev [P,6] or NULL*/,
                             const float *viewmatrix /*dev [16]*/, const float *projmatrix /*dev [16]*/,
                             const float *campos /*dev [3]*/, float tanfovx, float tanfovy, int prefiltered,
-                            int *radii /*dev [P] or NULL*/, void *geom_ws /*dev*/, void *stream);
+                            int *radii /*dev [P] or NULL*/, int *n_touched /*dev [P], zeroed here*/,
+                            void *geom_ws /*dev*/, void *image_ws /*dev*/, void *stream);
 /* Blocking: number of (Gaussian, tile) instances produced by phase A. */
-int gsaj_forward_num_rendered(int P, const void *geom_ws, void *stream, int *num_rendered /*host*/);
-/* Phase B: key emission, (tile, depth) sort, tile ranges, per-instance record gather,
+int gsaj_forward_num_rendered(int W, int H, const void *image_ws, void *stream, int *num_rendered /*host*/,
+                              int *max_tile_list /*host, may be NULL: longest per-tile list*/);
+/* Phase B: instance scatter into per-tile lists, per-tile (depth, id) sort in LDS (global radix
+ * sort of (tile, depth) keys if a tile list exceeds the LDS capacity), per-instance record gather,
  * front-to-back compositing.  out_color [3,H,W], out_depth [1,H,W], out_opacity [1,H,W],
  * n_touched [P] int32.  R must be the value phase A produced. */
-int gsaj_forward_render(int P, int R, int W, int H, const float *bg /*dev [3]*/,
+int gsaj_forward_render(int P, int R, int max_tile_list /* from phase A; < 0 forces the global-sort path */, int W, int H,
+                        const float *bg /*dev [3]*/,
                         const float *colors_precomp /*dev [P,3] or NULL*/, const int *radii /*dev [P] or NULL*/,
                         void *geom_ws, void *binning_ws, size_t binning_ws_bytes, void *image_ws,
                         float *out_color, float *out_depth, float *out_opacity, int *n_touched, void *stream);
@@ -131,8 +135,8 @@ int gsaj_debug_export(int P, int R, int W, int H, const void *geom_ws, const voi
  * bracketed by HIP events on the stream it is launched on.  gsaj_profile_end synchronises,
  * and returns per stage the summed duration in ms and the number of launches.
  * Stage order: GSAJ_STAGE_NAMES. */
-#define GSAJ_NUM_STAGES 11
-#define GSAJ_STAGE_NAMES "preprocess,scan_blocks,emit_keys,sort,ranges_records,render_fwd,render_bwd,gaussian_bwd,tau_finalize,dense_bwd,dense_reduce"
+#define GSAJ_NUM_STAGES 13
+#define GSAJ_STAGE_NAMES "preprocess,scan_blocks,emit_keys,sort,ranges_records,render_fwd,render_bwd,gaussian_bwd,tau_finalize,dense_bwd,dense_reduce,scatter_instances,tile_sort_records"
 int gsaj_profile_begin(int max_records);
 int gsaj_profile_end(float *stage_ms /*host [GSAJ_NUM_STAGES]*/, int *stage_launches /*host [GSAJ_NUM_STAGES]*/);
 

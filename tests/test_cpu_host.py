@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.gsaj_image_workspace_bytes(640, 480) >= 640 * 480 * 8
     assert lib.gsaj_dense_workspace_bytes(15, 640, 480) >= 1200 * 15 * 48
     # argument errors are reported through return code + gsaj_last_error (no GPU needed)
-    assert lib.gsaj_forward_preprocess(0, 0, 0, 640, 480, *([None] * 5), 1.0, *([None] * 5), 1.0, 1.0, 0, None, None, None) == -1
+    assert lib.gsaj_forward_preprocess(0, 0, 0, 640, 480, *([None] * 5), 1.0, *([None] * 5), 1.0, 1.0, 0, *([None] * 5)) == -1
     assert b"invalid argument" in lib.gsaj_last_error()
 
 

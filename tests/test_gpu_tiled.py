@@ -230,3 +230,38 @@ def test_dL_dtau_matches_finite_differences(torch_cuda):
         with torch.no_grad():
             num[k] = (float(loss_at(d)[1]) - float(loss_at(-d)[1])) / (2 * eps)
     assert np.abs(ana - num).max() < 1e-2 * np.abs(num).max(), (ana, num)
+
+
+@pytest.mark.parametrize("mode", ["forced", "oversized_tile"])
+def test_global_sort_fallback_path(torch_cuda, mode):
+    """Binning has two paths: per-tile LDS sort (lists <= 4096 entries) and the global radix sort of
+    (tile, depth) keys.  Both must give the oracle's order bit for bit."""
+    from gsaj import rasterizer as C
+    from gsaj import synthetic as syn
+    from oracle import oracle as orc
+
+    if mode == "forced":
+        cam, sc, deg = hp.make("p2000_160x120")
+    else:  # 6000 Gaussians on a 32x32 image: every tile list is longer than the LDS capacity
+        cam = hp.small_camera(32, 32, f=30.0, orthonormal=True)
+        sc = syn.make_scene(6000, 9, cam, z_range=(1.0, 3.0), log_scale_range=(np.log(0.2), np.log(0.5)), sh_coeffs=1,
+                            opacity_range=(0.01, 0.05), margin=-0.1)
+        deg = 0
+    (ref, st), kw = hp.oracle_forward(cam, sc, deg)
+    C.FORCE_GLOBAL_SORT = mode == "forced"
+    try:
+        out, args = hp.gpu_forward(cam, sc, deg, kw=kw)
+    finally:
+        C.FORCE_GLOBAL_SORT = False
+    R, color, radii, geom, binning, img, depth, opacity, n_touched = out
+    if mode == "oversized_tile":
+        assert (st["ranges"][:, 1] - st["ranges"][:, 0]).max() > 4096
+    dbg = {k: v.cpu().numpy() for k, v in C.debug_export(sc["means3D"].shape[0], R, cam["W"], cam["H"], geom, binning, img).items()}
+    np.testing.assert_array_equal(dbg["point_list"].astype(np.uint32), st["point_list"])
+    np.testing.assert_array_equal(dbg["ranges"], st["ranges"])
+    hp.assert_image_close(color.cpu().numpy(), ref["color"], IMG_TOL)
+    dLc, dLd = hp.seeds(cam, seed=3)
+    gref = orc.backward(st, dLc, dLd, cam["projmatrix_raw"])
+    g = hp.gpu_backward(cam, deg, out, args, dLc, dLd)
+    assert hp.rel_err(g[9].cpu().numpy(), gref["dL_dtau_sum"]) < GRAD_TOL
+    assert hp.rel_err(g[3].cpu().numpy(), gref["dL_dmean3D"]) < GRAD_TOL
