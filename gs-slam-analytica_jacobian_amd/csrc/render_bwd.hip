@@ -40,6 +40,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int gx, const 
   const int py = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
   const bool inside = px < W && py < H;
   const float pxf = (float)px, pyf = (float)py;
+  const float qx0 = (float)(tx * TILE + (wave & 1) * 8), qy0 = (float)(ty * TILE + (wave >> 1) * 8);
   const uint2 range = ranges[tile];
   const size_t pid = (size_t)py * W + px, HW = (size_t)H * W;
 
@@ -87,9 +88,21 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int gx, const 
 
     const uint32_t first_idx = lo - range.x;  // list index (0-based) of rec[0]
     if (wmax > first_idx) {
-      for (int j = n - 1; j >= 0; --j) {
-        const uint32_t idx = first_idx + (uint32_t)j;
-        if (idx >= wmax) continue;
+      for (int jb = ((n - 1) >> 6) << 6; jb >= 0; jb -= 64) {
+        // lane l tests entry jb+l against this wave's quadrant (and its furthest last contributor);
+        // the loop then visits only the set bits, back to front
+        bool rel = false;
+        if (jb + lane < n && first_idx + (uint32_t)(jb + lane) < wmax) {
+          const float4 q0 = rec[(jb + lane) * REC_F4 + 0];
+          const float4 q1 = rec[(jb + lane) * REC_F4 + 1];
+          rel = quadrant_relevant(q0.x, q0.y, q1.x, q1.y, q1.z, q1.w, qx0, qy0);
+        }
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(rel);
+        while (todo != 0ull) {
+          const int jj = 63 - __builtin_clzll(todo);
+          todo &= ~(1ull << jj);
+          const int j = jb + jj;
+          const uint32_t idx = first_idx + (uint32_t)j;
         const float4 r0 = rec[j * REC_F4 + 0];
         const float4 r1 = rec[j * REC_F4 + 1];
         const float dx = r0.x - pxf, dy = r0.y - pyf;
@@ -134,6 +147,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int gx, const 
         float x0, x1, x2;
         reduce10(v, x0, x1, x2);
         store10(acc + (j * 4 + wave) * IGRAD_F, lane, x0, x1, x2);
+        }
       }
     }
     __syncthreads();

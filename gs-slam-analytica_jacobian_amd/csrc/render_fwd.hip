@@ -13,6 +13,7 @@
 // with ONE atomic wave-instruction per 64 entries (the reference issues one atomic per
 // pixel per entry, forward.cu:512-514).
 #include "gsaj_common.h"
+#include "wave_reduce.h"
 
 #define FWD_ROUND 256
 
@@ -29,6 +30,7 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int gx, const 
   const int py = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
   const bool inside = px < W && py < H;
   const float pxf = (float)px, pyf = (float)py;
+  const float qx0 = (float)(tx * TILE + (wave & 1) * 8), qy0 = (float)(ty * TILE + (wave >> 1) * 8);
   const uint2 range = ranges[tile];
 
   bool done = !inside;
@@ -45,12 +47,22 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int gx, const 
       rec[tid * REC_F4 + 2] = src[2];
     }
     __syncthreads();
-    if (__ballot(!done) == 0ull) continue;  // this quadrant is finished; keep serving barriers
+    if (__builtin_amdgcn_ballot_w64(!done) == 0ull) continue;  // this quadrant is finished; keep serving barriers
     for (int jb = 0; jb < n; jb += 64) {
       const int m = min(64, n - jb);
+      // lane l tests entry jb+l against this wave's quadrant; the loop then visits only the set bits
+      bool rel = false;
+      if (lane < m) {
+        const float4 q0 = rec[(jb + lane) * REC_F4 + 0];
+        const float4 q1 = rec[(jb + lane) * REC_F4 + 1];
+        rel = quadrant_relevant(q0.x, q0.y, q1.x, q1.y, q1.z, q1.w, qx0, qy0);
+      }
+      unsigned long long todo = __builtin_amdgcn_ballot_w64(rel);
       int cnt = 0;  // lane l: #pixels of this wave that count entry jb+l as "touched"
-      int jj = 0;
-      for (; jj < m; jj++) {
+      bool wave_done = false;
+      while (todo != 0ull) {
+        const int jj = __builtin_ctzll(todo);
+        todo &= todo - 1ull;
         const int j = jb + jj;
         const float4 r0 = rec[j * REC_F4 + 0];
         const float4 r1 = rec[j * REC_F4 + 1];
@@ -63,7 +75,7 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int gx, const 
           done = true;
           ok = false;
         }
-        if (__ballot(ok) != 0ull) {
+        if (__builtin_amdgcn_ballot_w64(ok) != 0ull) {
           const float4 r2 = rec[j * REC_F4 + 2];
           if (ok) {
             const float w = alpha * T;
@@ -74,16 +86,19 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int gx, const 
             T = test_T;
             last = base - range.x + (uint32_t)j + 1u;
           }
-          const int touched = __popcll(__ballot(ok && test_T > 0.5f));
+          const int touched = __popcll(__builtin_amdgcn_ballot_w64(ok && test_T > 0.5f));
           cnt = (lane == jj) ? touched : cnt;  // each entry is visited once per 64-batch
         }
-        if (__ballot(!done) == 0ull) break;
+        if (__builtin_amdgcn_ballot_w64(!done) == 0ull) {
+          wave_done = true;
+          break;
+        }
       }
       if (lane < m && cnt > 0) {
         const uint32_t id = __float_as_uint(rec[(jb + lane) * REC_F4 + 0].w);
         atomicAdd(&n_touched[id], cnt);
       }
-      if (jj < m) break;  // whole quadrant saturated
+      if (wave_done) break;  // whole quadrant saturated
     }
   }
 

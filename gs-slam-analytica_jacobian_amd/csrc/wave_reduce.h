@@ -48,3 +48,34 @@ __device__ __forceinline__ void store10(float *a, int lane, float x0, float x1, 
     if ((r & 1) == 0) a[8 + (r >> 1)] = x2;
   }
 }
+
+// ---- lane-parallel relevance test of one list entry against an 8x8 pixel quadrant -----------------
+// Returns false only if NO pixel of the quadrant [X0, X0+7] x [Y0, Y0+7] can pass the compositor's
+// per-pixel tests (power <= 0 and alpha = o * exp(power) >= 1/255): the quadratic form
+// q = a dx^2 + 2 b dx dy + c dy^2 (power = -q/2) is minimised over the continuous box, and the
+// entry is dropped when o * exp(-q_min / 2) stays below 1/255 by a safety factor that covers the
+// fp32 / v_exp_f32 rounding of the per-pixel evaluation.  Non positive-definite conics are kept.
+// This only removes work whose result is "skip" for all 64 lanes -- results are unchanged.
+__device__ __forceinline__ bool quadrant_relevant(float mx, float my, float a, float b, float c, float o, float X0,
+                                                  float Y0) {
+  const float dxl = mx - (X0 + 7.0f), dxh = mx - X0;
+  const float dyl = my - (Y0 + 7.0f), dyh = my - Y0;
+  const bool pd = a > 0.f && c > 0.f && (a * c - b * b) > 0.f;
+  const bool inside = dxl <= 0.f && dxh >= 0.f && dyl <= 0.f && dyh >= 0.f;
+  const float ic = __builtin_amdgcn_rcpf(c), ia = __builtin_amdgcn_rcpf(a);
+  float q = 3.0e38f;
+  {
+    const float y0 = fminf(fmaxf(-b * dxl * ic, dyl), dyh);
+    q = fminf(q, a * dxl * dxl + 2.f * b * dxl * y0 + c * y0 * y0);
+    const float y1 = fminf(fmaxf(-b * dxh * ic, dyl), dyh);
+    q = fminf(q, a * dxh * dxh + 2.f * b * dxh * y1 + c * y1 * y1);
+    const float x0 = fminf(fmaxf(-b * dyl * ia, dxl), dxh);
+    q = fminf(q, a * x0 * x0 + 2.f * b * x0 * dyl + c * dyl * dyl);
+    const float x1 = fminf(fmaxf(-b * dyh * ia, dxl), dxh);
+    q = fminf(q, a * x1 * x1 + 2.f * b * x1 * dyh + c * dyh * dyh);
+  }
+  // keep if o * exp(-q/2) >= (1/255) * 0.99, evaluated conservatively (q shrunk by a relative 1e-3 and 1e-3 absolute)
+  const float qs = fmaxf(q * 0.999f - 1.0e-3f, 0.f);
+  const bool reach = o * __expf(-0.5f * qs) >= (0.99f / 255.0f);
+  return !pd || inside || reach;
+}
