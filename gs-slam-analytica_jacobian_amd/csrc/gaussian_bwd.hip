@@ -9,7 +9,10 @@
 // it first sums the partial gradients of its (tile, Gaussian) instances in emission order
 // (deterministic -- replaces the float atomics of backward.cu:852-869), keeps every
 // intermediate in registers, writes each output once, and the 6 pose components are reduced
-// wave -> workgroup -> a fixed-order final pass.  HBM-bound streaming stage.
+// wave -> (last-arriving workgroup) fixed-order final pass.  HBM-bound streaming stage: one wave per
+// workgroup (P/64 groups spread over the 256 CUs), the instance partials of a Gaussian are one
+// contiguous run (emission-slot order), and the [64][M*3] SH blocks are staged through LDS so that the
+// global loads / stores of dL_dsh are fully coalesced (padded LDS rows, conflict-free per-lane reads).
 #include "gsaj_common.h"
 
 __constant__ float bSH_C0 = 0.28209479177387814f;
@@ -91,13 +94,24 @@ __device__ __forceinline__ float3 sh_backward(int deg, float3 pos, float3 campos
   return dnormvdv(dorig, ddir);
 }
 
-__global__ __launch_bounds__(PRE_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g, uint32_t *__restrict__ counters,
-                                                            const uint32_t *__restrict__ inv_pos,
-                                                            const float4 *__restrict__ inst_grad) {
-  __shared__ float wsum[PRE_BLOCK / 64][6];
+__global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g, uint32_t *__restrict__ counters,
+                                                           const float4 *__restrict__ inst_grad) {
+  extern __shared__ float sh_lds[];  // [2][GB_BLOCK][3M+1]: SH coefficients in, dL/dSH out (padded rows)
   __shared__ uint32_t s_ticket;
   const int tid = threadIdx.x;
-  const int idx = blockIdx.x * PRE_BLOCK + tid;
+  const int idx = blockIdx.x * GB_BLOCK + tid;
+  const int shw = 3 * p.M, shs_stride = shw + 1;
+  float *sh_in = sh_lds, *sh_out = sh_lds + GB_BLOCK * shs_stride;
+  if (p.shs) {  // coalesced load of this workgroup's contiguous [GB_BLOCK][M*3] SH block
+    const size_t base = (size_t)blockIdx.x * GB_BLOCK * shw;
+    const int count = min(GB_BLOCK, p.P - blockIdx.x * GB_BLOCK) * shw;
+    for (int e = tid; e < count; e += GB_BLOCK) {
+      const int gi = e / shw, k = e - gi * shw;
+      sh_in[gi * shs_stride + k] = p.shs[base + e];
+      sh_out[gi * shs_stride + k] = 0.f;
+    }
+    __syncthreads();
+  }
   float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int radius = idx < p.P ? p.radii[idx] : 0;
   if (radius > 0) {
@@ -105,13 +119,28 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS 
     const uint32_t cnt = g.tiles_touched[idx];
     const uint32_t first = g.point_offsets[idx] - cnt;
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0;
-    for (uint32_t u = 0; u < cnt; u++) {
-      const uint32_t k = inv_pos[first + u];
-      const float4 *src = inst_grad + (size_t)k * REC_F4;
-      const float4 a0 = src[0], a1 = src[1], a2 = src[2];
-      s0.x += a0.x; s0.y += a0.y; s0.z += a0.z; s0.w += a0.w;
-      s1.x += a1.x; s1.y += a1.y; s1.z += a1.z; s1.w += a1.w;
-      s2.x += a2.x; s2.y += a2.y;
+    {
+      // 4 instances per trip with all 12 loads issued before the first use: this stage is
+      // latency-bound (P/64 waves on 1024 SIMDs), so memory-level parallelism is what counts.
+      // The summation order stays u = 0, 1, 2, ... (bit-reproducible).
+      const float4 *src = inst_grad + (size_t)first * REC_F4;
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (uint32_t u = 0; u < cnt; u += 4) {
+        float4 a[4][3];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const bool ok = u + q < cnt;
+          const float4 *r = src + (size_t)(ok ? u + q : u) * REC_F4;
+          a[q][0] = r[0]; a[q][1] = r[1]; a[q][2] = r[2];
+          if (!ok) { a[q][0] = z; a[q][1] = z; a[q][2] = z; }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          s0.x += a[q][0].x; s0.y += a[q][0].y; s0.z += a[q][0].z; s0.w += a[q][0].w;
+          s1.x += a[q][1].x; s1.y += a[q][1].y; s1.z += a[q][1].z; s1.w += a[q][1].w;
+          s2.x += a[q][2].x; s2.y += a[q][2].y;
+        }
+      }
     }
     const float g2x = s0.x, g2y = s0.y;           // dL/dmean2D (NDC-scaled)
     const float gcx = s0.z, gcy = s0.w, gcz = s1.x;  // dL/dconic a, b, c
@@ -235,11 +264,10 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS 
     // ---- 5. colour -> SH, view direction -> mean3D, tau ----
     if (p.shs) {
       const float3 cam = make_float3(p.campos[0], p.campos[1], p.campos[2]);
-      const float3 dmean = sh_backward(p.D, mean, cam, p.shs + (size_t)idx * p.M * 3, g.clamped + 3 * (size_t)idx, gcol,
-                                       p.dL_dsh + (size_t)idx * p.M * 3);
+      const float3 dmean = sh_backward(p.D, mean, cam, sh_in + tid * shs_stride, g.clamped + 3 * (size_t)idx, gcol,
+                                       sh_out + tid * shs_stride);
       gm.x += dmean.x; gm.y += dmean.y; gm.z += dmean.z;
       tau[0] -= dmean.x; tau[1] -= dmean.y; tau[2] -= dmean.z;
-      for (int k = (p.D + 1) * (p.D + 1) * 3; k < p.M * 3; k++) p.dL_dsh[(size_t)idx * p.M * 3 + k] = 0.f;
     }
     p.dL_dmean3D[3 * (size_t)idx] = gm.x; p.dL_dmean3D[3 * (size_t)idx + 1] = gm.y; p.dL_dmean3D[3 * (size_t)idx + 2] = gm.z;
     // ---- 6. cov3D -> scale, rotation ----
@@ -289,7 +317,6 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS 
     p.dL_ddepth[i] = 0.f;
 #pragma unroll
     for (int k = 0; k < 6; k++) p.dL_dcov3D[6 * i + k] = 0.f;
-    if (p.shs) for (int k = 0; k < p.M * 3; k++) p.dL_dsh[i * p.M * 3 + k] = 0.f;
     if (p.scales) {
 #pragma unroll
       for (int k = 0; k < 3; k++) p.dL_dscale[3 * i + k] = 0.f;
@@ -300,62 +327,63 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS 
       for (int k = 0; k < 6; k++) p.dL_dtau[6 * i + k] = 0.f;
     }
   }
-  // ---- 7. workgroup partial of dL/dtau (fixed reduction tree) ----
+  // ---- 7. dL/dSH block: coalesced store (rows of culled Gaussians and coefficients above the active
+  //         degree are zero) ----
+  if (p.shs) {
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * GB_BLOCK * shw;
+    const int count = min(GB_BLOCK, p.P - blockIdx.x * GB_BLOCK) * shw;
+    for (int e = tid; e < count; e += GB_BLOCK) {
+      const int gi = e / shw, k = e - gi * shw;
+      p.dL_dsh[base + e] = sh_out[gi * shs_stride + k];
+    }
+  }
+  // ---- 8. wave partial of dL/dtau (fixed butterfly) ----
 #pragma unroll
   for (int k = 0; k < 6; k++) {
     float v = tau[k];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if ((tid & 63) == 0) wsum[tid >> 6][k] = v;
-  }
-  __syncthreads();
-  if (tid < 6) {
-    float v = 0.f;
-#pragma unroll
-    for (int w = 0; w < PRE_BLOCK / 64; w++) v += wsum[w][tid];
-    g.tau_partials[(size_t)blockIdx.x * 8 + tid] = v;
+    if (tid == 0)  // write-through (sc1) store: part of the fence-free hand-off below
+      __hip_atomic_store(&g.tau_partials[(size_t)blockIdx.x * 8 + k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (!p.dL_dtau_sum) return;
-  // ---- 8. the last workgroup to arrive sums the partials in workgroup order (fp64): deterministic,
+  // ---- 9. the last workgroup to arrive sums the partials in workgroup order (fp64): deterministic,
   // no extra launch (replaces torch.sum over [P,6], diff_gaussian_rasterization/__init__.py:162).
-  // Hand-off: plain stores -> vmcnt(0) -> barrier -> agent release -> ticket; the last arriver
-  // acquires before reading the other workgroups' partials (cdna_hip_programming.md G16).
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  // Hand-off without fences (MI355X_MICROARCH.md, hand-offs measured with sc1 loads in place of the
+  // acquire): the 6 partials are stored write-through (sc1) by lane 0, drained with vmcnt(0), then
+  // the ticket is drawn with a relaxed agent-scope atomic; the workgroup that draws the last ticket
+  // reads every partial with sc1 loads only after its add has returned.  An agent release here
+  // (buffer_wbl2) would write back this kernel's ~25 MB of dirty output once per workgroup.
   if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     s_ticket = __hip_atomic_fetch_add(&counters[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (s_ticket == gridDim.x - 1) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
   }
   __syncthreads();
   if (s_ticket != gridDim.x - 1) return;
-  __shared__ double red[PRE_BLOCK];
   const int nblk = (int)gridDim.x;
+  double acc6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int i = tid; i < nblk; i += GB_BLOCK) {  // rows are independent loads: all in flight at once
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+      acc6[k] += (double)__hip_atomic_load(&g.tau_partials[(size_t)i * 8 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#pragma unroll
   for (int k = 0; k < 6; k++) {
-    double v = 0.0;
-    for (int i = tid; i < nblk; i += PRE_BLOCK)
-      v += (double)__hip_atomic_load(&g.tau_partials[(size_t)i * 8 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    red[tid] = v;
-    __syncthreads();
-    for (int o = PRE_BLOCK / 2; o > 0; o >>= 1) {
-      if (tid < o) red[tid] += red[tid + o];
-      __syncthreads();
-    }
-    if (tid == 0) p.dL_dtau_sum[k] = (float)red[0];
-    __syncthreads();
+    double v = acc6[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (tid == 0) p.dL_dtau_sum[k] = (float)v;
   }
   if (tid == 0) counters[3] = 0u;  // ready for the next backward over this workspace
 }
 
 int launch_gaussian_backward(const BwdParams &p, const GeomWS &g, const BinWS &b, const ImageWS &im, hipStream_t s) {
-  const int nblk = (p.P + PRE_BLOCK - 1) / PRE_BLOCK;
+  const int nblk = (p.P + GB_BLOCK - 1) / GB_BLOCK;
   {
     GsajProfScope ps(ST_GAUSSIAN_BWD, s);
-    hipLaunchKernelGGL(k_gaussian_bwd, dim3(nblk), dim3(PRE_BLOCK), 0, s, p, g, im.counters, b.inv_pos, b.inst_grad);
+    const size_t lds = p.shs ? sizeof(float) * 2 * GB_BLOCK * (3 * (size_t)p.M + 1) : 0;
+    hipLaunchKernelGGL(k_gaussian_bwd, dim3(nblk), dim3(GB_BLOCK), lds, s, p, g, im.counters, b.inst_grad);
   }
   GSAJ_HIP_CHECK(hipGetLastError());
   return GSAJ_OK;

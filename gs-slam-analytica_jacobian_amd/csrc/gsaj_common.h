@@ -9,14 +9,18 @@
 #define GSAJ_WAVE 64
 #define TILE GSAJ_TILE
 #define TILE_PIXELS (TILE * TILE)
-#define PRE_BLOCK 256   // Gaussians per workgroup in the per-Gaussian kernels
+#define PRE_BLOCK 256   // Gaussians per workgroup in the forward per-Gaussian kernels
+#define GB_BLOCK 64     // Gaussians per workgroup in the per-Gaussian backward (one wave: spreads P/64 groups over the CUs)
 #define REC_F4 3        // float4s per sorted-instance record
 #define IGRAD_F 12      // floats per per-instance gradient slot (10 used, padded to 3 x float4)
 
 // ---- per-instance record (one per (tile, Gaussian) pair, in sorted order) ---------------
 //   r0 = (mean2D.x, mean2D.y, depth, gaussian id as bits)
 //   r1 = (conic.a, conic.b, conic.c, opacity)
-//   r2 = (colour.r, colour.g, colour.b, unused)
+//   r2 = (colour.r, colour.g, colour.b, emission slot u as bits)
+// The emission slot u (= first slot of the Gaussian + index of the tile inside its rectangle) is
+// where the reverse compositor stores this instance's partial gradients, so that the per-Gaussian
+// backward reads each Gaussian's partials as one contiguous run.
 // Written once after the sort so that the compositors stream contiguous 48-B records
 // instead of gathering four arrays through an index (forward.cu:491-498 / backward.cu:742-752).
 
@@ -56,7 +60,7 @@ static inline __host__ __device__ size_t geom_carve(char *base, size_t P, GeomWS
   CARVE(point_offsets, uint32_t, P);
   CARVE(internal_radii, int, P);
   CARVE(block_sums, uint32_t, nblk);
-  CARVE(tau_partials, float, nblk * 8);
+  CARVE(tau_partials, float, ((P + GB_BLOCK - 1) / GB_BLOCK + 1) * 8);
   return off;
 }
 
@@ -98,9 +102,8 @@ struct BinWS {  // reference: BinningState, rasterizer_impl.h:55-66
   uint64_t *keys;           // [R]
   uint32_t *vals_unsorted;  // [R]
   uint32_t *point_list;     // [R] sorted Gaussian ids
-  uint32_t *inv_pos;        // [R] emission slot -> sorted position
   float4 *records;          // [R*3]
-  float4 *inst_grad;        // [R*3] per-instance partial gradients (backward)
+  float4 *inst_grad;        // [R*3] per-instance partial gradients (backward), indexed by emission slot
   char *sort_temp;
   size_t sort_temp_bytes;
 };
@@ -114,7 +117,6 @@ static inline size_t bin_carve(char *base, size_t R, size_t sort_temp_bytes, Bin
   CARVE(keys, uint64_t, Rn);
   CARVE(vals_unsorted, uint32_t, Rn);
   CARVE(point_list, uint32_t, Rn);
-  CARVE(inv_pos, uint32_t, Rn);
   CARVE(records, float4, Rn * REC_F4);
   CARVE(inst_grad, float4, Rn * REC_F4);
   CARVE(sort_temp, char, sort_temp_bytes);

@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void k_tile_sort_records(int gx, int gy, const
                                                            const float *__restrict__ features, GeomWS g, ImageWS im,
                                                            const uint64_t *__restrict__ inst_key,
                                                            uint32_t *__restrict__ point_list,
-                                                           float4 *__restrict__ records, uint32_t *__restrict__ inv_pos) {
+                                                           float4 *__restrict__ records) {
   __shared__ uint64_t keys[SORT_CAP];
   const int tid = threadIdx.x, tile = blockIdx.x;
   const uint32_t beg = im.tile_offset[tile * TILE_REP], end = im.tile_offset[(tile + 1) * TILE_REP];
@@ -382,12 +382,11 @@ __global__ __launch_bounds__(256) void k_tile_sort_records(int gx, int gy, const
     const float2 xy = g.means2D[id];
     records[(size_t)k * REC_F4 + 0] = make_float4(xy.x, xy.y, __uint_as_float((uint32_t)(key >> 32)), __uint_as_float(id));
     records[(size_t)k * REC_F4 + 1] = g.conic_opacity[id];
-    records[(size_t)k * REC_F4 + 2] =
-        make_float4(features[3 * (size_t)id], features[3 * (size_t)id + 1], features[3 * (size_t)id + 2], 0.f);
     int x0, y0, x1, y1;
     tile_rect(xy.x, xy.y, radii[id], gx, gy, x0, y0, x1, y1);
-    const uint32_t first = g.point_offsets[id] - g.tiles_touched[id];
-    inv_pos[first + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0))] = k;
+    const uint32_t u = g.point_offsets[id] - g.tiles_touched[id] + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
+    records[(size_t)k * REC_F4 + 2] = make_float4(features[3 * (size_t)id], features[3 * (size_t)id + 1],
+                                                  features[3 * (size_t)id + 2], __uint_as_float(u));
   }
 }
 
@@ -454,7 +453,7 @@ int launch_tile_binning(int P, int R, int grid_x, int grid_y, const int *radii, 
   {
     GsajProfScope ps(ST_TILE_SORT, s);
     hipLaunchKernelGGL(k_tile_sort_records, dim3(grid_x * grid_y), dim3(256), 0, s, grid_x, grid_y, radii, features, g, im,
-                       b.keys_unsorted, b.point_list, b.records, b.inv_pos);
+                       b.keys_unsorted, b.point_list, b.records);
   }
   GSAJ_HIP_CHECK(hipGetLastError());
   return GSAJ_OK;

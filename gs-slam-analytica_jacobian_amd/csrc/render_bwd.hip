@@ -68,8 +68,13 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int gx, const 
   float accC0 = 0.f, accC1 = 0.f, accC2 = 0.f, accD = 0.f;  // accum_rec, accum_rec_depth
 
   uint32_t hi = range.x + bmax;  // exclusive sorted position
-  // rows [hi, range.y) were never reached by any pixel of the tile: their partials are zero
-  for (uint32_t k = hi * REC_F4 + tid; k < range.y * REC_F4; k += 256) inst_grad[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // entries [hi, range.y) were never reached by any pixel of the tile: their partials are zero
+  for (uint32_t k = hi + tid; k < range.y; k += 256) {
+    float4 *dst = inst_grad + (size_t)__float_as_uint(records[(size_t)k * REC_F4 + 2].w) * REC_F4;
+    dst[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+    dst[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    dst[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 
   while (hi > range.x) {
     const uint32_t lo = (hi - range.x > BWD_ROUND) ? hi - BWD_ROUND : range.x;
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int gx, const 
         s2.x += b2.x; s2.y += b2.y;
       }
       s2.z = 0.f; s2.w = 0.f;
-      float4 *dst = inst_grad + (size_t)(lo + tid) * REC_F4;
+      float4 *dst = inst_grad + (size_t)__float_as_uint(rec[tid * REC_F4 + 2].w) * REC_F4;  // emission slot
       dst[0] = s0;
       dst[1] = s1;
       dst[2] = s2;
