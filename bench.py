@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sh-coeffs", type=int, default=0, help="experiment: keep only the first N SH coefficients per Gaussian")
     return ap.parse_args()
 
 
@@ -69,6 +70,8 @@ def main():
                                    cy=cam0["cy"])[rank]
     else:
         cam = cam0
+    if a.sh_coeffs:
+        sc["shs"] = np.ascontiguousarray(sc["shs"][:, : a.sh_coeffs])
     P, W, H = sc["means3D"].shape[0], cam["W"], cam["H"]
     M = sc["shs"].shape[1]
     deg = min(a.sh_degree, int(round(M ** 0.5)) - 1)

@@ -102,62 +102,98 @@ __global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g
   const int idx = blockIdx.x * GB_BLOCK + tid;
   const int shw = 3 * p.M, shs_stride = shw + 1;
   float *sh_in = sh_lds, *sh_out = sh_lds + GB_BLOCK * shs_stride;
-  if (p.shs) {  // coalesced load of this workgroup's contiguous [GB_BLOCK][M*3] SH block
+  // ---- 0. every input of this Gaussian is requested up front (this stage is latency-bound: one wave
+  //         per SIMD, so the loads must be in flight together, not one s_waitcnt apart) ----
+  const int radius = idx < p.P ? p.radii[idx] : 0;
+  const bool vis = radius > 0;
+  const size_t ii = (size_t)(idx < p.P ? idx : 0);
+  // emission slots: Gaussian idx owns rows [first, first + cnt) of inst_grad; consecutive Gaussians
+  // own consecutive runs, so the rows of this wave's 64 Gaussians are ONE contiguous block
+  const uint32_t cnt = idx < p.P ? g.tiles_touched[ii] : 0u;
+  const uint32_t endi = idx < p.P ? g.point_offsets[ii] : 0u;
+  const uint32_t first = endi - cnt;
+  const float3 mean = make_float3(p.means3D[3 * ii], p.means3D[3 * ii + 1], p.means3D[3 * ii + 2]);
+  float c6[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) c6[k] = p.cov3Ds[6 * ii + k];
+  float3 sc = make_float3(0.f, 0.f, 0.f);
+  float4 q = make_float4(1.f, 0.f, 0.f, 0.f);
+  if (p.scales) {
+    sc = make_float3(p.scales[3 * ii], p.scales[3 * ii + 1], p.scales[3 * ii + 2]);
+    q = reinterpret_cast<const float4 *>(p.rotations)[ii];
+  }
+  uint8_t cl[3] = {0, 0, 0};
+  if (p.shs) {
+    cl[0] = g.clamped[3 * ii]; cl[1] = g.clamped[3 * ii + 1]; cl[2] = g.clamped[3 * ii + 2];
+    // coalesced load of this workgroup's contiguous [GB_BLOCK][M*3] SH block, 12 loads per batch
     const size_t base = (size_t)blockIdx.x * GB_BLOCK * shw;
     const int count = min(GB_BLOCK, p.P - blockIdx.x * GB_BLOCK) * shw;
-    for (int e = tid; e < count; e += GB_BLOCK) {
-      const int gi = e / shw, k = e - gi * shw;
-      sh_in[gi * shs_stride + k] = p.shs[base + e];
-      sh_out[gi * shs_stride + k] = 0.f;
+    for (int e0 = 0; e0 < count; e0 += 12 * GB_BLOCK) {
+      float v[12];
+#pragma unroll
+      for (int b = 0; b < 12; b++) {
+        const int e = e0 + b * GB_BLOCK + tid;
+        v[b] = e < count ? p.shs[base + e] : 0.f;
+      }
+#pragma unroll
+      for (int b = 0; b < 12; b++) {
+        const int e = e0 + b * GB_BLOCK + tid;
+        if (e < count) {
+          const int gi = e / shw, k = e - gi * shw;
+          sh_in[gi * shs_stride + k] = v[b];
+          sh_out[gi * shs_stride + k] = 0.f;
+        }
+      }
     }
     __syncthreads();
   }
   float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const int radius = idx < p.P ? p.radii[idx] : 0;
-  if (radius > 0) {
-    // ---- 1. gather this Gaussian's instance partials (fixed order) ----
-    const uint32_t cnt = g.tiles_touched[idx];
-    const uint32_t first = g.point_offsets[idx] - cnt;
-    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0;
-    {
-      // 4 instances per trip with all 12 loads issued before the first use: this stage is
-      // latency-bound (P/64 waves on 1024 SIMDs), so memory-level parallelism is what counts.
-      // The summation order stays u = 0, 1, 2, ... (bit-reproducible).
-      const float4 *src = inst_grad + (size_t)first * REC_F4;
-      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (uint32_t u = 0; u < cnt; u += 4) {
-        float4 a[4][3];
+  // ---- 1. gather the instance partials.  Tiles-per-Gaussian is heavy-tailed (mean ~8, max > 100), so a
+  //         per-lane loop over global memory makes the whole wave wait for its largest Gaussian.
+  //         Instead the wave streams its contiguous block of rows through LDS with fully coalesced
+  //         loads (256 rows = 12 KB per trip, 12 loads per lane in flight) and each lane then sums its
+  //         own rows from LDS in emission order (bit-reproducible). ----
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0;
+  {
+    __shared__ float4 rows[256 * REC_F4];
+    const uint32_t F = (uint32_t)__shfl((int)first, 0);
+    uint32_t E = endi;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const bool ok = u + q < cnt;
-          const float4 *r = src + (size_t)(ok ? u + q : u) * REC_F4;
-          a[q][0] = r[0]; a[q][1] = r[1]; a[q][2] = r[2];
-          if (!ok) { a[q][0] = z; a[q][1] = z; a[q][2] = z; }
-        }
+    for (int o = 32; o > 0; o >>= 1) E = max(E, (uint32_t)__shfl_xor((int)E, o));
+    for (uint32_t lo = F; lo < E; lo += 256) {
+      const uint32_t hi = min(lo + 256u, E);
+      float4 a[4][3];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          s0.x += a[q][0].x; s0.y += a[q][0].y; s0.z += a[q][0].z; s0.w += a[q][0].w;
-          s1.x += a[q][1].x; s1.y += a[q][1].y; s1.z += a[q][1].z; s1.w += a[q][1].w;
-          s2.x += a[q][2].x; s2.y += a[q][2].y;
-        }
+      for (int w = 0; w < 4; w++) {
+        const uint32_t r = lo + (uint32_t)(w * GB_BLOCK + tid);
+        const float4 *src = inst_grad + (size_t)(r < hi ? r : lo) * REC_F4;
+        a[w][0] = src[0]; a[w][1] = src[1]; a[w][2] = src[2];
       }
+#pragma unroll
+      for (int w = 0; w < 4; w++) {
+        rows[(w * GB_BLOCK + tid) * REC_F4 + 0] = a[w][0];
+        rows[(w * GB_BLOCK + tid) * REC_F4 + 1] = a[w][1];
+        rows[(w * GB_BLOCK + tid) * REC_F4 + 2] = a[w][2];
+      }
+      __syncthreads();
+      const uint32_t ub = max(first, lo), ue = min(first + cnt, hi);
+      for (uint32_t u = ub; u < ue; u++) {
+        const float4 a0 = rows[(u - lo) * REC_F4 + 0], a1 = rows[(u - lo) * REC_F4 + 1], a2 = rows[(u - lo) * REC_F4 + 2];
+        s0.x += a0.x; s0.y += a0.y; s0.z += a0.z; s0.w += a0.w;
+        s1.x += a1.x; s1.y += a1.y; s1.z += a1.z; s1.w += a1.w;
+        s2.x += a2.x; s2.y += a2.y;
+      }
+      __syncthreads();
     }
+  }
+  if (vis) {
     const float g2x = s0.x, g2y = s0.y;           // dL/dmean2D (NDC-scaled)
     const float gcx = s0.z, gcy = s0.w, gcz = s1.x;  // dL/dconic a, b, c
     const float gop = s1.y;
     const float3 gcol = make_float3(s1.z, s1.w, s2.x);
     const float gz = s2.y;
-    p.dL_dmean2D[3 * (size_t)idx] = g2x; p.dL_dmean2D[3 * (size_t)idx + 1] = g2y; p.dL_dmean2D[3 * (size_t)idx + 2] = 0.f;
-    p.dL_dconic[4 * (size_t)idx] = gcx; p.dL_dconic[4 * (size_t)idx + 1] = gcy; p.dL_dconic[4 * (size_t)idx + 2] = 0.f;
-    p.dL_dconic[4 * (size_t)idx + 3] = gcz;
-    p.dL_dopacity[idx] = gop;
-    p.dL_dcolor[3 * (size_t)idx] = gcol.x; p.dL_dcolor[3 * (size_t)idx + 1] = gcol.y; p.dL_dcolor[3 * (size_t)idx + 2] = gcol.z;
-    p.dL_ddepth[idx] = gz;
-
     // ---- 2. conic -> cov2D -> cov3D, M = J Rcw, t ----
-    const float3 mean = make_float3(p.means3D[3 * (size_t)idx], p.means3D[3 * (size_t)idx + 1], p.means3D[3 * (size_t)idx + 2]);
     const float *vm = p.viewmatrix;
-    const float *c6 = p.cov3Ds + 6 * (size_t)idx;
     const float fx = p.focal_x, fy = p.focal_y;
     float3 t = xform4x3(vm, mean);
     const float3 pC = t;  // un-clamped camera-space point
@@ -264,16 +300,20 @@ __global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g
     // ---- 5. colour -> SH, view direction -> mean3D, tau ----
     if (p.shs) {
       const float3 cam = make_float3(p.campos[0], p.campos[1], p.campos[2]);
-      const float3 dmean = sh_backward(p.D, mean, cam, sh_in + tid * shs_stride, g.clamped + 3 * (size_t)idx, gcol,
+      const float3 dmean = sh_backward(p.D, mean, cam, sh_in + tid * shs_stride, cl, gcol,
                                        sh_out + tid * shs_stride);
       gm.x += dmean.x; gm.y += dmean.y; gm.z += dmean.z;
       tau[0] -= dmean.x; tau[1] -= dmean.y; tau[2] -= dmean.z;
     }
+    p.dL_dmean2D[3 * (size_t)idx] = g2x; p.dL_dmean2D[3 * (size_t)idx + 1] = g2y; p.dL_dmean2D[3 * (size_t)idx + 2] = 0.f;
+    p.dL_dconic[4 * (size_t)idx] = gcx; p.dL_dconic[4 * (size_t)idx + 1] = gcy; p.dL_dconic[4 * (size_t)idx + 2] = 0.f;
+    p.dL_dconic[4 * (size_t)idx + 3] = gcz;
+    p.dL_dopacity[idx] = gop;
+    p.dL_dcolor[3 * (size_t)idx] = gcol.x; p.dL_dcolor[3 * (size_t)idx + 1] = gcol.y; p.dL_dcolor[3 * (size_t)idx + 2] = gcol.z;
+    p.dL_ddepth[idx] = gz;
     p.dL_dmean3D[3 * (size_t)idx] = gm.x; p.dL_dmean3D[3 * (size_t)idx + 1] = gm.y; p.dL_dmean3D[3 * (size_t)idx + 2] = gm.z;
     // ---- 6. cov3D -> scale, rotation ----
     if (p.scales) {
-      const float3 sc = make_float3(p.scales[3 * (size_t)idx], p.scales[3 * (size_t)idx + 1], p.scales[3 * (size_t)idx + 2]);
-      const float4 q = reinterpret_cast<const float4 *>(p.rotations)[idx];
       const float r = q.x, x = q.y, y = q.z, z = q.w;
       const float R[3][3] = {{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
                              {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
