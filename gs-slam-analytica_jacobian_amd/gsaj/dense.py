@@ -1,0 +1,112 @@
+"""The reference's CPU/NumPy analytic path on the GPU ("dense" semantics).
+
+Mirrors the functions of Loss_Derivative_script_compare.py that produce the committed goldens
+grad_mu_I_pixel.npy, grad_Sigma_I_pixel.npy, grad_depth_per_gaussian.npy and dL_dtau.npy:
+
+  compute_gradients_2D(...)                    <- compute_gradients_2D_vectorized_chunked (:1173-1351)
+  render_projected(...)                        <- rendered_Image_from_Projected_Gaussians_vectorized (:973-1018)
+  compute_analytical_jacobians_all_gaussians   <- same name (:705-760), closed form of GetAnalyticalJcobian (:633-703)
+  assemble_dL_dtau(...)                        <- the module-level chain-rule loop (:1587-1695)
+
+All arithmetic runs in libgsaj_hip.so; torch only holds the device buffers.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from .rasterizer import _stream
+
+_F, _D = torch.float32, torch.float64
+
+
+def _dev(x, dtype, device):
+    return torch.as_tensor(np.ascontiguousarray(x) if isinstance(x, np.ndarray) else x, dtype=dtype, device=device).contiguous()
+
+
+def l1_seeds(rendered_color, rendered_depth, gt_color, gt_depth, mask):
+    """Per-pixel dL/dC (H,W,3), dL/dD (H,W) of the summed masked L1 loss (compare.py:1212-1224)."""
+    m = mask.to(rendered_color.dtype)
+    gc = torch.sign(rendered_color - gt_color) * m[..., None]
+    gd = torch.sign(rendered_depth - gt_depth) * ((gt_depth > 0.0) & mask.bool()).to(rendered_depth.dtype)
+    return gc, gd
+
+
+def compute_gradients_2D(means_2D, covs_2D, colors, depths, alphas, grad_color, grad_depth, device="cuda:0"):
+    """Depth-sorted projected Gaussians + per-pixel seeds -> (grad_mu_I [N,2], grad_Sigma_I [N,2,2],
+    grad_depth_per_gaussian [N], grad_color_per_gaussian [N,3]), fp32, rows in sorted order."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    m2, c2 = _dev(means_2D, _F, dev), _dev(covs_2D, _F, dev)
+    col, dep, op = _dev(colors, _F, dev), _dev(depths, _F, dev), _dev(alphas, _F, dev).reshape(-1)
+    gc, gd = _dev(grad_color, _F, dev), _dev(grad_depth, _F, dev)
+    N = m2.shape[0]
+    H, W = gd.shape
+    assert gc.shape == (H, W, 3) and c2.shape == (N, 2, 2)
+    g_mu = torch.empty((N, 2), dtype=_F, device=dev)
+    g_S = torch.empty((N, 2, 2), dtype=_F, device=dev)
+    g_z = torch.empty((N,), dtype=_F, device=dev)
+    g_c = torch.empty((N, 3), dtype=_F, device=dev)
+    ws = torch.empty(lib.gsaj_dense_workspace_bytes(N, W, H), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gsaj_dense_backward(N, W, H, m2.data_ptr(), c2.data_ptr(), col.data_ptr(), dep.data_ptr(),
+                                           op.data_ptr(), gc.data_ptr(), gd.data_ptr(), g_mu.data_ptr(), g_S.data_ptr(),
+                                           g_z.data_ptr(), g_c.data_ptr(), ws.data_ptr(), _stream(dev)),
+                   "gsaj_dense_backward")
+    return g_mu, g_S, g_z, g_c
+
+
+def render_projected(means_2D, covs_2D, colors, depths, alphas, H, W, device="cuda:0"):
+    """Dense forward compositor -> colour (H,W,3), depth (H,W)."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    m2, c2 = _dev(means_2D, _F, dev), _dev(covs_2D, _F, dev)
+    col, dep, op = _dev(colors, _F, dev), _dev(depths, _F, dev), _dev(alphas, _F, dev).reshape(-1)
+    N = m2.shape[0]
+    img = torch.empty((H, W, 3), dtype=_F, device=dev)
+    d = torch.empty((H, W), dtype=_F, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gsaj_dense_render(N, W, H, m2.data_ptr(), c2.data_ptr(), col.data_ptr(), dep.data_ptr(),
+                                         op.data_ptr(), img.data_ptr(), d.data_ptr(), _stream(dev)), "gsaj_dense_render")
+    return img, d
+
+
+def compute_analytical_jacobians_all_gaussians(mu_W_all_homo, gaussian_3D_covs, T_cw, fx, fy, W, H, device="cuda:0"):
+    """-> dmu_I_dT_all (N,2,6), dcov_I_dT_all (N,4,6), fp64, original index order; the mu-Jacobian is
+    in NDC units (x 2fx/W, 2fy/H), the Sigma-Jacobian rows in pixel^2 units (compare.py:724-754)."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    mu = _dev(np.asarray(mu_W_all_homo)[:, :3], _D, dev)
+    cov = _dev(gaussian_3D_covs, _D, dev)
+    T = _dev(np.asarray(T_cw, np.float64).reshape(16), _D, dev)
+    N = mu.shape[0]
+    dmu = torch.empty((N, 2, 6), dtype=_D, device=dev)
+    dcov = torch.empty((N, 4, 6), dtype=_D, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gsaj_pose_jacobians(N, T.data_ptr(), mu.data_ptr(), cov.data_ptr(), float(fx), float(fy), int(W),
+                                           int(H), dmu.data_ptr(), dcov.data_ptr(), _stream(dev)), "gsaj_pose_jacobians")
+    return dmu, dcov
+
+
+def assemble_dL_dtau(order, grad_mu, grad_Sigma, grad_depth, grad_color, dmu_all, dcov_all, xyz_world, T_cw, campos,
+                     shs, sh_degree=3, device="cuda:0"):
+    """dL/dtau (6,) fp64 and its four parts (mu, cov, depth, sh) of the NumPy path."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    N = len(order)
+    o = _dev(np.asarray(order, np.int32), torch.int32, dev)
+    gm, gS = _dev(grad_mu, _F, dev), _dev(grad_Sigma, _F, dev)
+    gz, gc = _dev(grad_depth, _F, dev), _dev(grad_color, _F, dev)
+    dmu, dcov = _dev(dmu_all, _D, dev), _dev(dcov_all, _D, dev)
+    mu = _dev(np.asarray(xyz_world)[:, :3], _D, dev)
+    T = _dev(np.asarray(T_cw, np.float64).reshape(16), _D, dev)
+    cp = _dev(campos, _D, dev)
+    sh = _dev(shs, _D, dev)
+    M = sh.shape[1]
+    out = torch.empty(6, dtype=_D, device=dev)
+    parts = torch.empty((4, 6), dtype=_D, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gsaj_dense_tau(N, M, int(sh_degree), o.data_ptr(), gm.data_ptr(), gS.data_ptr(), gz.data_ptr(),
+                                      gc.data_ptr(), dmu.data_ptr(), dcov.data_ptr(), mu.data_ptr(), T.data_ptr(),
+                                      cp.data_ptr(), sh.data_ptr(), out.data_ptr(), parts.data_ptr(), _stream(dev)),
+                   "gsaj_dense_tau")
+    return out, dict(mu=parts[0], cov=parts[1], depth=parts[2], sh=parts[3])
