@@ -54,10 +54,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU product path)"
+    if os.environ.get("GSAJ_SHARE_DEVICE") == "1":  # rehearsal on a 1-GPU box: every rank on cuda:0 (gloo only)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("GSAJ_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
 
     from gsaj import synthetic as syn
