@@ -23,19 +23,24 @@ def bucket_layout(M, has_scales=True):
     return fields
 
 
-def bucket_views(bucket, P, M, has_scales=True):
-    """Split a flat [P * sum(widths)] tensor into per-field [P, w] views (field-major, so each
-    field is one contiguous region the kernels can write)."""
+def bucket_views(bucket, P, M, has_scales=True, n_keyframes=0):
+    """Split a flat tensor into per-field [P, w] views (field-major, so each field is one contiguous
+    region the kernels can write).  With n_keyframes > 0 the bucket ends with a [n_keyframes, 6] block
+    "tau_all": every rank writes the dL/dtau of its own keyframes there and leaves the other rows
+    zero, so the SAME sum all-reduce also all-gathers the pose gradients (no second collective)."""
     out, off = {}, 0
     for name, w in bucket_layout(M, has_scales):
         out[name] = bucket[off:off + P * w].view(P, w)
         off += P * w
+    if n_keyframes:
+        out["tau_all"] = bucket[off:off + 6 * n_keyframes].view(n_keyframes, 6)
+        off += 6 * n_keyframes
     assert off == bucket.numel()
     return out
 
 
-def bucket_numel(P, M, has_scales=True):
-    return P * sum(w for _, w in bucket_layout(M, has_scales))
+def bucket_numel(P, M, has_scales=True, n_keyframes=0):
+    return P * sum(w for _, w in bucket_layout(M, has_scales)) + 6 * n_keyframes
 
 
 def shard_keyframes(n_keyframes, world_size, rank):
@@ -43,11 +48,14 @@ def shard_keyframes(n_keyframes, world_size, rank):
     return list(range(rank, n_keyframes, world_size))
 
 
-def allreduce_gaussian_grads(bucket, group=None):
-    """Sum the per-Gaussian gradient bucket over all ranks in place (one collective)."""
+def allreduce_gaussian_grads(bucket, group=None, async_op=False):
+    """Sum the per-Gaussian gradient bucket over all ranks in place (one collective).
+    With async_op=True the work handle is returned: call .wait() before the bucket is read or
+    overwritten, so the collective of one step overlaps the kernels of the next."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
-    return bucket
+        work = dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        return work if async_op else bucket
+    return None if async_op else bucket
 
 
 def gather_pose_grads(tau_local, n_keyframes, group=None):

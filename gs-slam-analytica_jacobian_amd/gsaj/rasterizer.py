@@ -239,7 +239,8 @@ class FrameContext:
     size (the tracking / mapping inner loop): no allocation and two C-ABI calls per step.
     The binning workspace grows geometrically when a frame produces more instances."""
 
-    def __init__(self, P, W, H, M, device, has_scales=True, per_gaussian_tau=False):
+    def __init__(self, P, W, H, M, device, has_scales=True, per_gaussian_tau=False, grad_slots=1, n_keyframes=0,
+                 keyframe=0):
         lib = _lib.load()
         self.lib, self.P, self.W, self.H, self.M, self.dev = lib, P, W, H, M, torch.device(device)
         f = dict(device=self.dev, dtype=_F32)
@@ -254,16 +255,24 @@ class FrameContext:
         self.binning = torch.empty(0, **byte)
         self.R = 0
         # per-Gaussian parameter gradients live in ONE flat bucket (field-major) so that a multi-GPU
-        # mapping step can all-reduce it with a single collective (gsaj.keyframe_shard)
+        # mapping step can all-reduce it with a single collective (gsaj.keyframe_shard); `grad_slots`
+        # buckets let the collective of step i overlap the kernels of step i+1
         from .keyframe_shard import bucket_numel, bucket_views
-        self.bucket = torch.zeros(bucket_numel(P, M, has_scales), **f)
-        v = bucket_views(self.bucket, P, M, has_scales)
-        self.g = dict(
-            mean2D=torch.zeros((P, 3), **f), conic=torch.zeros((P, 2, 2), **f), opacity=v["opacity"],
-            color=torch.zeros((P, 3), **f), depth=torch.zeros((P, 1), **f), mean3D=v["mean3D"],
-            cov3D=v["cov3D"] if not has_scales else torch.zeros((P, 6), **f), sh=v["sh"].view(P, M, 3),
-            scale=v.get("scale"), rot=v.get("rot"),
-            tau=torch.zeros((P, 6), **f) if per_gaussian_tau else None, tau_sum=torch.zeros((6,), **f))
+        self.buckets, self.slots = [], []
+        for _ in range(max(1, grad_slots)):
+            bucket = torch.zeros(bucket_numel(P, M, has_scales, n_keyframes), **f)
+            v = bucket_views(bucket, P, M, has_scales, n_keyframes)
+            self.buckets.append(bucket)
+            self.slots.append(dict(
+                mean2D=torch.zeros((P, 3), **f), conic=torch.zeros((P, 2, 2), **f), opacity=v["opacity"],
+                color=torch.zeros((P, 3), **f), depth=torch.zeros((P, 1), **f), mean3D=v["mean3D"],
+                cov3D=v["cov3D"] if not has_scales else torch.zeros((P, 6), **f), sh=v["sh"].view(P, M, 3),
+                scale=v.get("scale"), rot=v.get("rot"),
+                tau=torch.zeros((P, 6), **f) if per_gaussian_tau else None,
+                # with keyframes the 6 pose gradients land in this rank's row of the shared tau block
+                tau_sum=v["tau_all"][keyframe] if n_keyframes else torch.zeros((6,), **f),
+                tau_all=v.get("tau_all")))
+        self.bucket, self.g = self.buckets[0], self.slots[0]
 
     def _ensure_binning(self, R):
         need = self.lib.gsaj_binning_workspace_bytes(R)
@@ -291,8 +300,10 @@ class FrameContext:
 
     def backward(self, bg, means3D, viewmatrix, projmatrix, projmatrix_raw, campos, tanfovx, tanfovy, dL_dcolor, dL_ddepth,
                  sh_degree=0, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None,
-                 scale_modifier=1.0):
-        g = self.g
+                 scale_modifier=1.0, slot=0):
+        g = self.slots[slot]
+        if g["tau_all"] is not None:
+            g["tau_all"].zero_()  # rows of the other ranks' keyframes must be zero before the sum all-reduce
         _lib.check(self.lib.gsaj_rasterize_backward(
             self.P, int(sh_degree), self.M, self.R, _ptr(bg), self.W, self.H, _ptr(means3D), _ptr(shs),
             _ptr(colors_precomp), _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp),

@@ -207,6 +207,8 @@ def test_keyframe_shard_bucket_layout():
     v = ks.bucket_views(b, P, M)
     assert v["mean3D"].shape == (P, 3) and v["sh"].shape == (P, 48) and v["rot"].shape == (P, 4)
     assert ks.bucket_numel(P, M) == P * 59
+    v2 = ks.bucket_views(torch.zeros(ks.bucket_numel(P, M, True, 8)), P, M, True, 8)
+    assert v2["tau_all"].shape == (8, 6)
     v["rot"].zero_()
     assert float(b[-P * 4:].abs().sum()) == 0  # views alias the bucket
     assert ks.shard_keyframes(10, 4, 1) == [1, 5, 9]
@@ -233,6 +235,15 @@ tot = sum(k + 1 for k in range(K))
 assert torch.all(v["mean3D"] == tot) and torch.all(v["sh"] == 10 * tot) and torch.all(v["rot"] == 0)
 for k in range(K):
     assert torch.equal(allt[k], torch.arange(6) + 100.0 * k), (k, allt[k])
+# pose gradients riding in the bucket tail: the sum all-reduce doubles as the all-gather
+b2 = torch.zeros(ks.bucket_numel(P, M, True, K))
+v2 = ks.bucket_views(b2, P, M, True, K)
+for k in mine:
+    v2["tau_all"][k] = torch.arange(6) + 100.0 * k
+work = ks.allreduce_gaussian_grads(b2, async_op=True)
+work.wait()
+for k in range(K):
+    assert torch.equal(v2["tau_all"][k], torch.arange(6) + 100.0 * k)
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
