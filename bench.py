@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync", action="store_true", help="read the instance count back on the host every frame")
     ap.add_argument("--sh-coeffs", type=int, default=0, help="experiment: keep only the first N SH coefficients per Gaussian")
     return ap.parse_args()
 
@@ -100,8 +101,9 @@ def main():
         if pending[slot] is not None:
             pending[slot].wait()  # stream-level: the bucket is about to be overwritten
             pending[slot] = None
+        # first frame: synchronous (sizes the binning arena); afterwards no host round trip per frame
         ctx.forward(bg, means, opac, view, proj, campos, cam["tanfovx"], cam["tanfovy"], sh_degree=deg, shs=shs,
-                    scales=scales, rotations=rots)
+                    scales=scales, rotations=rots, sync=(counter[0] == 1) or a.sync)
         g = ctx.backward(bg, means, view, proj, proj_raw, campos, cam["tanfovx"], cam["tanfovy"], dLc, dLd,
                          sh_degree=deg, shs=shs, scales=scales, rotations=rots, slot=slot)
         if world > 1:  # one collective: per-Gaussian grads summed, per-keyframe dL/dtau gathered (bucket tail)
@@ -124,8 +126,8 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    R, _ = ctx.status()  # raises if any asynchronous frame was aborted on the device (arena too small)
     inter = ctx.interactions()
-    R = ctx.R
 
     # same K steps again with every kernel bracketed by HIP events on its launch stream
     fence()

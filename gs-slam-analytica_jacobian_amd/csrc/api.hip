@@ -94,6 +94,17 @@ int gsaj_forward_preprocess(int P, int D, int M, int W, int H, const float *mean
                             const float *viewmatrix, const float *projmatrix, const float *campos, float tanfovx,
                             float tanfovy, int prefiltered, int *radii, int *n_touched, void *geom_ws, void *image_ws,
                             void *stream) {
+  return gsaj_forward_preprocess_cap(P, D, M, W, H, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
+                                     cov3D_precomp, viewmatrix, projmatrix, campos, tanfovx, tanfovy, prefiltered, radii,
+                                     n_touched, geom_ws, image_ws, 0, stream);
+}
+
+int gsaj_forward_preprocess_cap(int P, int D, int M, int W, int H, const float *means3D, const float *shs,
+                                const float *colors_precomp, const float *opacities, const float *scales,
+                                float scale_modifier, const float *rotations, const float *cov3D_precomp,
+                                const float *viewmatrix, const float *projmatrix, const float *campos, float tanfovx,
+                                float tanfovy, int prefiltered, int *radii, int *n_touched, void *geom_ws, void *image_ws,
+                                int capacity, void *stream) {
   if (P <= 0 || W <= 0 || H <= 0 || !means3D || !opacities || !viewmatrix || !projmatrix || !geom_ws || !image_ws ||
       !n_touched) {
     gsaj_set_error("gsaj_forward_preprocess: invalid argument (P=%d W=%d H=%d)", P, W, H);
@@ -124,6 +135,7 @@ int gsaj_forward_preprocess(int P, int D, int M, int W, int H, const float *mean
   p.focal_x = W / (2.0f * tanfovx);
   p.prefiltered = prefiltered;
   p.grid_x = (W + TILE - 1) / TILE; p.grid_y = (H + TILE - 1) / TILE;
+  p.capacity = capacity;
   ImageWS im;
   image_carve(align_base(image_ws), W, H, &im);
   return launch_preprocess(p, radii ? radii : g.internal_radii, n_touched, g, im, (hipStream_t)stream);
@@ -141,14 +153,34 @@ int gsaj_forward_num_rendered(int W, int H, const void *image_ws, void *stream, 
   GSAJ_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
   *num_rendered = (int)host[0];
   if (max_tile_list) *max_tile_list = (int)host[2];
-  if (host[1] == 1u) {
+  if (host[1] & ERR_PREFILTERED) {
     gsaj_set_error("Point is filtered although prefiltered is set. This shouldn't happen!");
     return GSAJ_ERR_PREFILTERED_CULLED;
   }
-  if (host[1] != 0u) {
+  if (host[1] & ERR_INTERNAL) {
     gsaj_set_error("internal error: tile histogram total != instance total");
     return GSAJ_ERR_HIP;
   }
+  if (host[1] & (ERR_CAPACITY | ERR_TILE_LIST)) {
+    gsaj_set_error("async forward aborted: %s (R=%u, longest tile list=%u)",
+                   (host[1] & ERR_CAPACITY) ? "binning arena too small" : "a tile list exceeds the LDS sort capacity", host[0],
+                   host[2]);
+    return GSAJ_ERR_WORKSPACE_TOO_SMALL;
+  }
+  return GSAJ_OK;
+}
+
+int gsaj_forward_aborted_count(int W, int H, const void *image_ws, void *stream, int *count) {
+  if (W <= 0 || H <= 0 || !image_ws || !count) {
+    gsaj_set_error("gsaj_forward_aborted_count: invalid argument");
+    return GSAJ_ERR_INVALID_ARGUMENT;
+  }
+  ImageWS im;
+  image_carve(align_base(const_cast<void *>(image_ws)), W, H, &im);
+  uint32_t host = 0;
+  GSAJ_HIP_CHECK(hipMemcpyAsync(&host, im.sticky, sizeof(host), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  GSAJ_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  *count = (int)host;
   return GSAJ_OK;
 }
 
@@ -208,6 +240,42 @@ int gsaj_rasterize_forward(int P, int D, int M, const float *bg, int W, int H, c
   rc = gsaj_forward_render(P, R, max_tile, W, H, bg, colors_precomp, radii, geom_ws, binning_ws, binning_ws_bytes, image_ws,
                            out_color, out_depth, out_opacity, n_touched, stream);
   return rc == GSAJ_OK ? R : rc;
+}
+
+int gsaj_rasterize_forward_async(int P, int D, int M, const float *bg, int W, int H, const float *means3D, const float *shs,
+                                 const float *colors_precomp, const float *opacities, const float *scales,
+                                 float scale_modifier, const float *rotations, const float *cov3D_precomp,
+                                 const float *viewmatrix, const float *projmatrix, const float *campos, float tanfovx,
+                                 float tanfovy, int prefiltered, float *out_color, float *out_depth, float *out_opacity,
+                                 int *radii, int *n_touched, void *geom_ws, void *binning_ws, size_t binning_ws_bytes,
+                                 int capacity, void *image_ws, void *stream) {
+  if (capacity <= 0 || !binning_ws || !bg || !out_color || !out_depth || !out_opacity || !n_touched) {
+    gsaj_set_error("gsaj_rasterize_forward_async: invalid argument");
+    return GSAJ_ERR_INVALID_ARGUMENT;
+  }
+  if (binning_ws_bytes < gsaj_binning_workspace_bytes(capacity)) {
+    gsaj_set_error("binning workspace smaller than gsaj_binning_workspace_bytes(capacity=%d)", capacity);
+    return GSAJ_ERR_WORKSPACE_TOO_SMALL;
+  }
+  int rc = gsaj_forward_preprocess_cap(P, D, M, W, H, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
+                                       rotations, cov3D_precomp, viewmatrix, projmatrix, campos, tanfovx, tanfovy,
+                                       prefiltered, radii, n_touched, geom_ws, image_ws, capacity, stream);
+  if (rc != GSAJ_OK) return rc;
+  // No host round trip: grids do not depend on R, the arena is carved for `capacity` instances, and
+  // k_scan aborts the frame on the device if R or a tile list does not fit (gsaj_forward_num_rendered
+  // reports it whenever the caller chooses to look).
+  hipStream_t s = (hipStream_t)stream;
+  GeomWS g;
+  geom_carve(align_base(geom_ws), (size_t)P, &g);
+  ImageWS im;
+  image_carve(align_base(image_ws), W, H, &im);
+  BinWS b;
+  bin_carve(align_base(binning_ws), (size_t)capacity, gsaj_sort_temp_bytes(capacity), &b);
+  const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+  const int *rad = radii ? radii : g.internal_radii;
+  const float *features = colors_precomp ? colors_precomp : g.rgb;
+  if ((rc = launch_tile_binning(P, capacity, gx, gy, rad, features, g, b, im, s)) != GSAJ_OK) return rc;
+  return launch_render_forward(W, H, gx, gy, bg, b, im, out_color, out_depth, out_opacity, n_touched, s);
 }
 
 int gsaj_rasterize_backward(int P, int D, int M, int R, const float *bg, int W, int H, const float *means3D,

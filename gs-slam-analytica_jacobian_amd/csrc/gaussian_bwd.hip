@@ -98,6 +98,7 @@ __global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g
                                                            const float4 *__restrict__ inst_grad) {
   extern __shared__ float sh_lds[];  // [2][GB_BLOCK][3M+1]: SH coefficients in, dL/dSH out (padded rows)
   __shared__ uint32_t s_ticket;
+  if (counters[4]) return;  // aborted async frame
   const int tid = threadIdx.x;
   const int idx = blockIdx.x * GB_BLOCK + tid;
   const int shw = 3 * p.M, shs_stride = shw + 1;

@@ -67,7 +67,12 @@ static inline __host__ __device__ size_t geom_carve(char *base, size_t P, GeomWS
 #define TILE_REP 1        // replicas of each tile's instance counter (1: contention is removed by LDS aggregation)
 #define LDS_TILES_MAX 8192  // images with more tiles than this bin with direct global atomics
 #define SORT_CAP 4096     // largest tile list the in-LDS tile sort handles; longer lists -> global radix fallback
-#define N_COUNTERS 64     // frame counters: [0] num_rendered [1] error flag [2] longest tile list [3] tau ticket
+#define N_COUNTERS 64     // frame counters: [0] num_rendered [1] error flags [2] longest tile list [3] tau ticket
+                          //   [4] abort (async forward: arena too small / tile list too long -> later kernels return)
+#define ERR_PREFILTERED 1u
+#define ERR_INTERNAL 2u
+#define ERR_CAPACITY 4u   // async forward: R exceeds the binning arena the caller provided
+#define ERR_TILE_LIST 8u  // async forward: a tile list exceeds SORT_CAP (the sync API falls back to the global sort)
 
 struct ImageWS {  // reference: ImageState, rasterizer_impl.h:46-53
   float *final_T;         // [H*W]
@@ -77,6 +82,7 @@ struct ImageWS {  // reference: ImageState, rasterizer_impl.h:46-53
   uint32_t *tile_count;   // [tiles*TILE_REP]         | zeroed by ONE memset per forward
   uint32_t *tile_cursor;  // [tiles*TILE_REP]        -+
   uint32_t *tile_offset;  // [tiles*TILE_REP + 1] exclusive scan of tile_count (tile-major)
+  uint32_t *sticky;       // [16] never zeroed by a forward: [0] number of aborted async forwards
   size_t zero_bytes;      // bytes from counters to the end of tile_cursor
 };
 
@@ -94,6 +100,7 @@ static inline __host__ __device__ size_t image_carve(char *base, int W, int H, I
   CARVE(tile_cursor, uint32_t, tiles * TILE_REP);
   if (g) g->zero_bytes = off - z0;
   CARVE(tile_offset, uint32_t, tiles * TILE_REP + 1);
+  CARVE(sticky, uint32_t, 16);
   return off;
 }
 
@@ -157,6 +164,7 @@ struct FwdParams {
   float scale_modifier, tanfovx, tanfovy, focal_x, focal_y;
   int prefiltered;
   int grid_x, grid_y;
+  int capacity;  // > 0: async forward, binning arena holds this many instances
 };
 
 int launch_preprocess(const FwdParams &p, int *radii, int *n_touched, const GeomWS &g, const ImageWS &im, hipStream_t s);

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__re
     const float3 p_orig = ld3(p.means3D, idx);
     const float3 p_view = xform4x3(p.viewmatrix, p_orig);
     if (p_view.z <= 0.2f) {
-      if (p.prefiltered) im.counters[1] = 1u;  // the reference traps here (auxiliary.h:156-160)
+      if (p.prefiltered) atomicOr(&im.counters[1], ERR_PREFILTERED);  // the reference traps here (auxiliary.h:156-160)
     } else {
       const float4 p_hom = xform4x4(p.projmatrix, p_orig);
       const float p_w = 1.0f / (p_hom.w + 0.0000001f);
@@ -246,7 +246,8 @@ __device__ uint32_t block_exclusive_scan(const uint32_t *__restrict__ in, uint32
 // One launch, one workgroup: (1) exclusive offsets of the per-workgroup Gaussian totals and the
 // grand total R; (2) exclusive offsets of the replicated per-tile histogram in tile-major order, so
 // a tile's list is the contiguous union of its replicas' segments; (3) the longest tile list.
-__global__ __launch_bounds__(1024) void k_scan(int nblk, int tiles, uint32_t *__restrict__ block_sums, ImageWS im) {
+__global__ __launch_bounds__(1024) void k_scan(int nblk, int tiles, int capacity, uint32_t *__restrict__ block_sums,
+                                               ImageWS im) {
   __shared__ uint32_t smax[16];
   const int tid = threadIdx.x;
   const uint32_t R = block_exclusive_scan(block_sums, block_sums, nblk, nullptr);
@@ -267,7 +268,17 @@ __global__ __launch_bounds__(1024) void k_scan(int nblk, int tiles, uint32_t *__
     im.tile_offset[tiles * TILE_REP] = R2;
     im.counters[0] = R;
     im.counters[2] = m;
-    if (R2 != R) im.counters[1] = 2u;  // cannot happen; guards the invariant sum(tile lists) == sum(tiles_touched)
+    uint32_t err = 0u;
+    if (R2 != R) err |= ERR_INTERNAL;  // cannot happen; guards the invariant sum(tile lists) == sum(tiles_touched)
+    if (capacity > 0) {  // async forward: nobody on the host will look at R before the next kernels run
+      if (R > (uint32_t)capacity) err |= ERR_CAPACITY;
+      if (m > SORT_CAP) err |= ERR_TILE_LIST;
+      if (err) {
+        im.counters[4] = 1u;  // the remaining kernels of this frame return immediately
+        atomicAdd(&im.sticky[0], 1u);
+      }
+    }
+    if (err) atomicOr(&im.counters[1], err);
   }
 }
 
@@ -280,6 +291,7 @@ __global__ __launch_bounds__(1024) void k_scan(int nblk, int tiles, uint32_t *__
 __global__ __launch_bounds__(PRE_BLOCK) void k_scatter_instances(int P, int gx, int gy, const int *__restrict__ radii,
                                                                  GeomWS g, ImageWS im, uint64_t *__restrict__ inst_key) {
   extern __shared__ uint32_t lds[];  // [2*tiles]: count -> reserved base, fill cursor
+  if (im.counters[4]) return;  // aborted async frame
   const int tid = threadIdx.x;
   const int idx = blockIdx.x * PRE_BLOCK + tid;
   const int tiles = gx * gy;
@@ -332,6 +344,7 @@ __global__ __launch_bounds__(256) void k_tile_sort_records(int gx, int gy, const
                                                            uint32_t *__restrict__ point_list,
                                                            float4 *__restrict__ records) {
   __shared__ uint64_t keys[SORT_CAP];
+  if (im.counters[4]) return;  // aborted async frame
   const int tid = threadIdx.x, tile = blockIdx.x;
   const uint32_t beg = im.tile_offset[tile * TILE_REP], end = im.tile_offset[(tile + 1) * TILE_REP];
   const int n = (int)(end - beg);
@@ -433,7 +446,7 @@ int launch_preprocess(const FwdParams &p, int *radii, int *n_touched, const Geom
   }
   {
     GsajProfScope ps(ST_SCAN, s);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, nblk, p.grid_x * p.grid_y, g.block_sums, im);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, nblk, p.grid_x * p.grid_y, p.capacity, g.block_sums, im);
   }
   GSAJ_HIP_CHECK(hipGetLastError());
   return GSAJ_OK;

@@ -29,8 +29,10 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int gx, const 
                                                     const uint32_t *__restrict__ n_contrib,
                                                     const float *__restrict__ dL_dpix,
                                                     const float *__restrict__ dL_dpix_depth,
-                                                    float4 *__restrict__ inst_grad) {
+                                                    float4 *__restrict__ inst_grad,
+                                                    const uint32_t *__restrict__ counters) {
   __shared__ float4 rec[BWD_ROUND * REC_F4];
+  if (counters[4]) return;  // aborted async frame
   __shared__ float acc[BWD_ROUND * 4 * IGRAD_F];  // [entry][wave][12]
   __shared__ uint32_t wave_max[4];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -179,11 +181,11 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int gx, const 
 
 int launch_render_backward(int R, int W, int H, int grid_x, int grid_y, const float *bg, const BinWS &b,
                            const ImageWS &im, const float *dL_dpix, const float *dL_dpix_depth, hipStream_t s) {
-  if (R <= 0) return GSAJ_OK;
+  if (R <= 0) return GSAJ_OK;  // (async callers pass the arena capacity as R)
   {
     GsajProfScope ps(ST_RENDER_BWD, s);
     hipLaunchKernelGGL(k_render_bwd, dim3(grid_x * grid_y), dim3(256), 0, s, W, H, grid_x, im.ranges, b.records, bg,
-                     im.final_T, im.n_contrib, dL_dpix, dL_dpix_depth, b.inst_grad);
+                     im.final_T, im.n_contrib, dL_dpix, dL_dpix_depth, b.inst_grad, im.counters);
   }
   GSAJ_HIP_CHECK(hipGetLastError());
   return GSAJ_OK;

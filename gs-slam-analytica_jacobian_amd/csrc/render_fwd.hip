@@ -21,8 +21,10 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int gx, const 
                                                     const float4 *__restrict__ records, const float *__restrict__ bg,
                                                     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                                                     float *__restrict__ out_color, float *__restrict__ out_depth,
-                                                    float *__restrict__ out_opacity, int *__restrict__ n_touched) {
+                                                    float *__restrict__ out_opacity, int *__restrict__ n_touched,
+                                                    const uint32_t *__restrict__ counters) {
   __shared__ float4 rec[FWD_ROUND * REC_F4];
+  if (counters[4]) return;  // aborted async frame
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int tile = blockIdx.x;
   const int ty = tile / gx, tx = tile - ty * gx;
@@ -120,7 +122,7 @@ int launch_render_forward(int W, int H, int grid_x, int grid_y, const float *bg,
   {
     GsajProfScope ps(ST_RENDER_FWD, s);
     hipLaunchKernelGGL(k_render_fwd, dim3(grid_x * grid_y), dim3(256), 0, s, W, H, grid_x, im.ranges, b.records, bg,
-                     im.final_T, im.n_contrib, out_color, out_depth, out_opacity, n_touched);
+                     im.final_T, im.n_contrib, out_color, out_depth, out_opacity, n_touched, im.counters);
   }
   GSAJ_HIP_CHECK(hipGetLastError());
   return GSAJ_OK;

@@ -251,9 +251,10 @@ class FrameContext:
         self.radii = torch.zeros((P,), device=self.dev, dtype=torch.int32)
         self.n_touched = torch.zeros((P,), device=self.dev, dtype=torch.int32)
         self.geom = torch.empty(lib.gsaj_geom_workspace_bytes(P), **byte)
-        self.img = torch.empty(lib.gsaj_image_workspace_bytes(W, H), **byte)
+        self.img = torch.zeros(lib.gsaj_image_workspace_bytes(W, H), **byte)  # zeroed: holds the sticky abort counter
         self.binning = torch.empty(0, **byte)
         self.R = 0
+        self.capacity = 0  # > 0 once an arena has been sized: enables forward(sync=False)
         # per-Gaussian parameter gradients live in ONE flat bucket (field-major) so that a multi-GPU
         # mapping step can all-reduce it with a single collective (gsaj.keyframe_shard); `grad_slots`
         # buckets let the collective of step i overlap the kernels of step i+1
@@ -277,11 +278,39 @@ class FrameContext:
     def _ensure_binning(self, R):
         need = self.lib.gsaj_binning_workspace_bytes(R)
         if self.binning.numel() < need:
-            self.binning = torch.empty(int(need * 1.25) + 4096, device=self.dev, dtype=torch.uint8)
+            self.capacity = int(R * 1.5) + 1024
+            self.binning = torch.empty(self.lib.gsaj_binning_workspace_bytes(self.capacity), device=self.dev,
+                                       dtype=torch.uint8)
+
+    def status(self):
+        """Blocking: (num_rendered, longest tile list) of the last forward; raises if it was aborted."""
+        R, mt = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(self.lib.gsaj_forward_num_rendered(self.W, self.H, self.img.data_ptr(), _stream(self.dev),
+                                                      ctypes.byref(R), ctypes.byref(mt)), "gsaj_forward_num_rendered")
+        self.true_R = R.value
+        n = ctypes.c_int(0)
+        _lib.check(self.lib.gsaj_forward_aborted_count(self.W, self.H, self.img.data_ptr(), _stream(self.dev),
+                                                       ctypes.byref(n)), "gsaj_forward_aborted_count")
+        if n.value:
+            raise _lib.GsajError("%d asynchronous forward(s) were aborted on the device (binning arena too small)" % n.value)
+        return R.value, mt.value
 
     def forward(self, bg, means3D, opacities, viewmatrix, projmatrix, campos, tanfovx, tanfovy, sh_degree=0, shs=None,
-                colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, scale_modifier=1.0):
+                colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, scale_modifier=1.0, sync=True):
+        """sync=True: read R back (16-byte D2H, the reference's only sync) and size the arena exactly.
+        sync=False: no host round trip at all -- the arena sized by an earlier synchronous frame (x1.5)
+        is reused and an overflowing frame aborts on the device; call status() when convenient."""
         lib, st = self.lib, _stream(self.dev)
+        if not sync and self.capacity > 0:
+            _lib.check(lib.gsaj_rasterize_forward_async(
+                self.P, int(sh_degree), self.M, _ptr(bg), self.W, self.H, _ptr(means3D), _ptr(shs), _ptr(colors_precomp),
+                _ptr(opacities), _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp),
+                _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tanfovx), float(tanfovy), 0,
+                self.color.data_ptr(), self.depth.data_ptr(), self.opacity.data_ptr(), self.radii.data_ptr(),
+                self.n_touched.data_ptr(), self.geom.data_ptr(), self.binning.data_ptr(), self.binning.numel(),
+                self.capacity, self.img.data_ptr(), st), "gsaj_rasterize_forward_async")
+            self.R = self.capacity  # what the backward must be given (arena carving)
+            return self.R
         _lib.check(lib.gsaj_forward_preprocess(
             self.P, int(sh_degree), self.M, self.W, self.H, _ptr(means3D), _ptr(shs), _ptr(colors_precomp),
             _ptr(opacities), _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix),
@@ -292,6 +321,7 @@ class FrameContext:
                    "gsaj_forward_num_rendered")
         self.R, self.max_tile_list = R.value, mt.value
         self._ensure_binning(self.R)
+        self.true_R = self.R
         _lib.check(lib.gsaj_forward_render(
             self.P, self.R, -1 if FORCE_GLOBAL_SORT else self.max_tile_list, self.W, self.H, _ptr(bg), _ptr(colors_precomp), self.radii.data_ptr(), self.geom.data_ptr(),
             self.binning.data_ptr(), self.binning.numel(), self.img.data_ptr(), self.color.data_ptr(),
@@ -317,5 +347,5 @@ class FrameContext:
 
     def interactions(self):
         """sum over pixels of n_contrib = Gaussian-pixel interactions of the last forward."""
-        dbg = debug_export(self.P, self.R, self.W, self.H, self.geom, self.binning, self.img)
+        dbg = debug_export(self.P, self.R, self.W, self.H, self.geom, self.binning, self.img)  # only n_contrib is used
         return int(dbg["n_contrib"].to(torch.int64).sum().item())

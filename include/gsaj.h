@@ -99,6 +99,36 @@ int gsaj_rasterize_forward(int P, int D, int M, const float *bg, int W, int H,
                            void *geom_ws, void *binning_ws, size_t binning_ws_bytes, void *image_ws,
                            int *num_rendered_out /*host, may be NULL*/, void *stream);
 
+/* ---- forward without any host synchronisation (tracking / mapping inner loops) -----------------
+ * The caller provides a binning workspace sized for `capacity` instances
+ * (gsaj_binning_workspace_bytes(capacity)) and passes the SAME capacity as `R` to
+ * gsaj_rasterize_backward.  If the frame needs more instances than that, or a tile list longer than
+ * the in-LDS sort handles, the frame is aborted on the device (outputs undefined) and
+ * gsaj_forward_num_rendered -- which may be called at any later time -- returns
+ * GSAJ_ERR_WORKSPACE_TOO_SMALL together with the R to size the arena for; the caller then repeats
+ * the frame (with a larger arena, or through the synchronising entry points, which also have the
+ * global-sort fallback). */
+int gsaj_rasterize_forward_async(int P, int D, int M, const float *bg, int W, int H,
+                                 const float *means3D, const float *shs, const float *colors_precomp,
+                                 const float *opacities, const float *scales, float scale_modifier,
+                                 const float *rotations, const float *cov3D_precomp,
+                                 const float *viewmatrix, const float *projmatrix, const float *campos,
+                                 float tanfovx, float tanfovy, int prefiltered,
+                                 float *out_color, float *out_depth, float *out_opacity, int *radii, int *n_touched,
+                                 void *geom_ws, void *binning_ws, size_t binning_ws_bytes, int capacity,
+                                 void *image_ws, void *stream);
+/* Blocking: number of async forwards aborted on the device since the image workspace was zeroed by
+ * the caller (the caller zero-fills the image workspace once, when it allocates it). */
+int gsaj_forward_aborted_count(int W, int H, const void *image_ws, void *stream, int *count /*host*/);
+/* gsaj_forward_preprocess with the arena capacity check armed (capacity = 0: unchecked). */
+int gsaj_forward_preprocess_cap(int P, int D, int M, int W, int H,
+                                const float *means3D, const float *shs, const float *colors_precomp,
+                                const float *opacities, const float *scales, float scale_modifier,
+                                const float *rotations, const float *cov3D_precomp,
+                                const float *viewmatrix, const float *projmatrix, const float *campos,
+                                float tanfovx, float tanfovy, int prefiltered, int *radii, int *n_touched,
+                                void *geom_ws, void *image_ws, int capacity, void *stream);
+
 /* ---- backward ------------------------------------------------------------------------ */
 /* dL_dpix [3,H,W], dL_dpix_depth [1,H,W] -> dL_dmean2D [P,3] (NDC-scaled, z unused),
  * dL_dconic [P,2,2] (slots 0,1,3), dL_dopacity [P], dL_dcolor [P,3], dL_ddepth [P],

@@ -265,3 +265,40 @@ def test_global_sort_fallback_path(torch_cuda, mode):
     g = hp.gpu_backward(cam, deg, out, args, dLc, dLd)
     assert hp.rel_err(g[9].cpu().numpy(), gref["dL_dtau_sum"]) < GRAD_TOL
     assert hp.rel_err(g[3].cpu().numpy(), gref["dL_dmean3D"]) < GRAD_TOL
+
+
+def test_async_forward_matches_sync_and_reports_overflow(torch_cuda):
+    """FrameContext.forward(sync=False): no host round trip; same bits as the synchronous path; a frame
+    that does not fit the arena is aborted on the device and reported by status()."""
+    import torch
+    from gsaj import _lib
+    from gsaj.rasterizer import FrameContext
+
+    cam, sc, deg = hp.make("p6000_640x480_sh1")
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)  # noqa: E731
+    P, M = sc["means3D"].shape[0], sc["shs"].shape[1]
+    args = dict(bg=torch.zeros(3, device=dev), means3D=t(sc["means3D"]), opacities=t(sc["opacities"]),
+                viewmatrix=t(cam["viewmatrix"]), projmatrix=t(cam["projmatrix"]), campos=t(cam["campos"]),
+                tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], sh_degree=deg, shs=t(sc["shs"]), scales=t(sc["scales"]),
+                rotations=t(sc["rotations"]))
+    dLc, dLd = hp.seeds(cam, seed=4)
+    bargs = dict(bg=args["bg"], means3D=args["means3D"], viewmatrix=args["viewmatrix"], projmatrix=args["projmatrix"],
+                 projmatrix_raw=t(cam["projmatrix_raw"]), campos=args["campos"], tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"],
+                 dL_dcolor=t(dLc), dL_ddepth=t(dLd), sh_degree=deg, shs=args["shs"], scales=args["scales"],
+                 rotations=args["rotations"])
+    ctx = FrameContext(P, cam["W"], cam["H"], M, dev)
+    ctx.forward(**args, sync=True)
+    g = ctx.backward(**bargs)
+    ref = [ctx.color.clone(), ctx.depth.clone(), ctx.n_touched.clone(), ctx.bucket.clone(), g["tau_sum"].clone()]
+    R_true = ctx.R
+    ctx.forward(**args, sync=False)
+    g = ctx.backward(**bargs)
+    assert ctx.status()[0] == R_true
+    for a, b in zip(ref, [ctx.color, ctx.depth, ctx.n_touched, ctx.bucket, g["tau_sum"]]):
+        assert torch.equal(a, b)
+    # shrink the arena below R: the frame must abort on the device and be reported
+    ctx.capacity = R_true // 2
+    ctx.forward(**args, sync=False)
+    with pytest.raises(_lib.GsajError, match="too small|aborted"):
+        ctx.status()
