@@ -4,9 +4,9 @@
 // alpha < 1/255 skipped, stop before T(1-alpha) < 1e-4, n_touched counts T(1-alpha) > 0.5.
 //
 // MI355X mapping: one 256-thread workgroup per 16x16 tile = four wave64s, each owning an
-// 8x8 pixel quadrant (one pixel per lane).  A round stages 256 sorted 48-byte instance
-// records in LDS with coalesced loads; the entry loop reads them back as wave-uniform
-// (broadcast) ds_read_b128s.  All early-outs are wave-level ballots -- a quadrant whose
+// 8x8 pixel quadrant (one pixel per lane).  Each wave stages 64 sorted 48-byte instance
+// records at a time in its private LDS area with coalesced loads; the entry loop reads them
+// back as wave-uniform (broadcast) ds_read_b128s.  All early-outs are wave-level ballots -- a quadrant whose
 // 64 pixels have all saturated stops walking the list, and entries that no lane of the
 // quadrant accepts skip the colour fetch -- instead of the reference's block-wide votes.
 // n_touched is accumulated into one register per 64 entries (lane l counts entry l) and flushed
@@ -15,7 +15,7 @@
 #include "gsaj_common.h"
 #include "wave_reduce.h"
 
-#define FWD_ROUND 256
+#define FWD_CHUNK 64  // records staged per wave per trip
 
 __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int gx, const uint2 *__restrict__ ranges,
                                                     const float4 *__restrict__ records, const float *__restrict__ bg,
@@ -23,9 +23,13 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int gx, const 
                                                     float *__restrict__ out_color, float *__restrict__ out_depth,
                                                     float *__restrict__ out_opacity, int *__restrict__ n_touched,
                                                     const uint32_t *__restrict__ counters) {
-  __shared__ float4 rec[FWD_ROUND * REC_F4];
+  // Each wave (one 8x8 quadrant) walks the tile list on its own: private 64-record staging area, no
+  // workgroup barrier anywhere, so a quadrant never waits for a slower neighbour.  The four waves of a
+  // tile read the same records; the repeats are served by L1/L2.
+  __shared__ float4 rec_all[4 * FWD_CHUNK * REC_F4];
   if (counters[4]) return;  // aborted async frame
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  float4 *rec = rec_all + wave * FWD_CHUNK * REC_F4;
   const int tile = blockIdx.x;
   const int ty = tile / gx, tx = tile - ty * gx;
   const int px = tx * TILE + (wave & 1) * 8 + (lane & 7);
@@ -39,65 +43,70 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int gx, const 
   float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f, Dp = 0.f;
   uint32_t last = 0;
 
-  for (uint32_t base = range.x; base < range.y; base += FWD_ROUND) {
-    if (__syncthreads_and(done)) break;  // also fences reuse of rec[]
-    const int n = min((uint32_t)FWD_ROUND, range.y - base);
-    if (tid < n) {
-      const float4 *src = records + (size_t)(base + tid) * REC_F4;
-      rec[tid * REC_F4 + 0] = src[0];
-      rec[tid * REC_F4 + 1] = src[1];
-      rec[tid * REC_F4 + 2] = src[2];
-    }
-    __syncthreads();
-    if (__builtin_amdgcn_ballot_w64(!done) == 0ull) continue;  // this quadrant is finished; keep serving barriers
-    for (int jb = 0; jb < n; jb += 64) {
-      const int m = min(64, n - jb);
-      // lane l tests entry jb+l against this wave's quadrant; the loop then visits only the set bits
+  if (__builtin_amdgcn_ballot_w64(!done) != 0ull) {
+    for (uint32_t base = range.x; base < range.y; base += FWD_CHUNK) {
+      const int m = min((uint32_t)FWD_CHUNK, range.y - base);
+      // stage: lane l fetches record base+l (coalesced 3 KB), tests it against the quadrant, publishes it
       bool rel = false;
       if (lane < m) {
-        const float4 q0 = rec[(jb + lane) * REC_F4 + 0];
-        const float4 q1 = rec[(jb + lane) * REC_F4 + 1];
+        const float4 *src = records + (size_t)(base + lane) * REC_F4;
+        const float4 q0 = src[0], q1 = src[1], q2 = src[2];
+        rec[lane * REC_F4 + 0] = q0;
+        rec[lane * REC_F4 + 1] = q1;
+        rec[lane * REC_F4 + 2] = q2;
         rel = quadrant_relevant(q0.x, q0.y, q1.x, q1.y, q1.z, q1.w, qx0, qy0);
       }
       unsigned long long todo = __builtin_amdgcn_ballot_w64(rel);
-      int cnt = 0;  // lane l: #pixels of this wave that count entry jb+l as "touched"
+      int cnt = 0;  // lane l: #pixels of this wave that count entry base+l as "touched"
       bool wave_done = false;
-      while (todo != 0ull) {
-        const int jj = __builtin_ctzll(todo);
+      if (todo != 0ull) {
+        // software pipeline: the geometry of the NEXT relevant record is requested from LDS before the
+        // current one is evaluated (its colour row is fetched only if some lane accepts the entry)
+        int jn = __builtin_ctzll(todo);
         todo &= todo - 1ull;
-        const int j = jb + jj;
-        const float4 r0 = rec[j * REC_F4 + 0];
-        const float4 r1 = rec[j * REC_F4 + 1];
-        const float dx = r0.x - pxf, dy = r0.y - pyf;
-        const float power = -0.5f * (r1.x * dx * dx + r1.z * dy * dy) - r1.y * dx * dy;
-        const float alpha = fminf(0.99f, r1.w * __expf(power));
-        const float test_T = T * (1.f - alpha);
-        bool ok = !done && power <= 0.0f && alpha >= (1.0f / 255.0f);
-        if (ok && test_T < 0.0001f) {
-          done = true;
-          ok = false;
-        }
-        if (__builtin_amdgcn_ballot_w64(ok) != 0ull) {
-          const float4 r2 = rec[j * REC_F4 + 2];
-          if (ok) {
-            const float w = alpha * T;
-            Cr += r2.x * w;
-            Cg += r2.y * w;
-            Cb += r2.z * w;
-            Dp += r0.z * w;
-            T = test_T;
-            last = base - range.x + (uint32_t)j + 1u;
+        float4 n0 = rec[jn * REC_F4 + 0], n1 = rec[jn * REC_F4 + 1];
+        while (true) {
+          const int jj = jn;
+          const float4 r0 = n0, r1 = n1;
+          const bool more = todo != 0ull;
+          if (more) {
+            jn = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            n0 = rec[jn * REC_F4 + 0];
+            n1 = rec[jn * REC_F4 + 1];
           }
-          const int touched = __popcll(__builtin_amdgcn_ballot_w64(ok && test_T > 0.5f));
-          cnt = (lane == jj) ? touched : cnt;  // each entry is visited once per 64-batch
-        }
-        if (__builtin_amdgcn_ballot_w64(!done) == 0ull) {
-          wave_done = true;
-          break;
+          const float dx = r0.x - pxf, dy = r0.y - pyf;
+          const float power = -0.5f * (r1.x * dx * dx + r1.z * dy * dy) - r1.y * dx * dy;
+          const float alpha = fminf(0.99f, r1.w * __expf(power));
+          const float test_T = T * (1.f - alpha);
+          bool ok = !done && power <= 0.0f && alpha >= (1.0f / 255.0f);
+          if (ok && test_T < 0.0001f) {  // this pixel is saturated: stop before this entry
+            done = true;
+            ok = false;
+          }
+          if (__builtin_amdgcn_ballot_w64(ok) != 0ull) {
+            const float4 r2 = rec[jj * REC_F4 + 2];
+            if (ok) {
+              const float w = alpha * T;
+              Cr += r2.x * w;
+              Cg += r2.y * w;
+              Cb += r2.z * w;
+              Dp += r0.z * w;
+              T = test_T;
+              last = base - range.x + (uint32_t)jj + 1u;
+            }
+            const int touched = __popcll(__builtin_amdgcn_ballot_w64(ok && test_T > 0.5f));
+            cnt = (lane == jj) ? touched : cnt;  // each entry is visited once per chunk
+          }
+          if (__builtin_amdgcn_ballot_w64(!done) == 0ull) {
+            wave_done = true;
+            break;
+          }
+          if (!more) break;
         }
       }
       if (lane < m && cnt > 0) {
-        const uint32_t id = __float_as_uint(rec[(jb + lane) * REC_F4 + 0].w);
+        const uint32_t id = __float_as_uint(rec[lane * REC_F4 + 0].w);
         atomicAdd(&n_touched[id], cnt);
       }
       if (wave_done) break;  // whole quadrant saturated
