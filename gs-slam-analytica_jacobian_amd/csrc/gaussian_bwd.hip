@@ -94,6 +94,8 @@ __device__ __forceinline__ float3 sh_backward(int deg, float3 pos, float3 campos
   return dnormvdv(dorig, ddir);
 }
 
+// SHW = 3*M as a compile-time constant (0: runtime) -- the staging loops divide by it per element
+template <int SHW>
 __global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g, uint32_t *__restrict__ counters,
                                                            const float4 *__restrict__ inst_grad) {
   extern __shared__ float sh_lds[];  // [2][GB_BLOCK][3M+1]: SH coefficients in, dL/dSH out (padded rows)
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g
   if (counters[4]) return;  // aborted async frame
   const int tid = threadIdx.x;
   const int idx = blockIdx.x * GB_BLOCK + tid;
-  const int shw = 3 * p.M, shs_stride = shw + 1;
+  const int shw = SHW > 0 ? SHW : 3 * p.M, shs_stride = shw + 1;
   float *sh_in = sh_lds, *sh_out = sh_lds + GB_BLOCK * shs_stride;
   // ---- 0. every input of this Gaussian is requested up front (this stage is latency-bound: one wave
   //         per SIMD, so the loads must be in flight together, not one s_waitcnt apart) ----
@@ -424,7 +426,13 @@ int launch_gaussian_backward(const BwdParams &p, const GeomWS &g, const BinWS &b
   {
     GsajProfScope ps(ST_GAUSSIAN_BWD, s);
     const size_t lds = p.shs ? sizeof(float) * 2 * GB_BLOCK * (3 * (size_t)p.M + 1) : 0;
-    hipLaunchKernelGGL(k_gaussian_bwd, dim3(nblk), dim3(GB_BLOCK), lds, s, p, g, im.counters, b.inst_grad);
+    switch (p.shs ? p.M : -1) {
+      case 1: hipLaunchKernelGGL(k_gaussian_bwd<3>, dim3(nblk), dim3(GB_BLOCK), lds, s, p, g, im.counters, b.inst_grad); break;
+      case 4: hipLaunchKernelGGL(k_gaussian_bwd<12>, dim3(nblk), dim3(GB_BLOCK), lds, s, p, g, im.counters, b.inst_grad); break;
+      case 9: hipLaunchKernelGGL(k_gaussian_bwd<27>, dim3(nblk), dim3(GB_BLOCK), lds, s, p, g, im.counters, b.inst_grad); break;
+      case 16: hipLaunchKernelGGL(k_gaussian_bwd<48>, dim3(nblk), dim3(GB_BLOCK), lds, s, p, g, im.counters, b.inst_grad); break;
+      default: hipLaunchKernelGGL(k_gaussian_bwd<0>, dim3(nblk), dim3(GB_BLOCK), lds, s, p, g, im.counters, b.inst_grad); break;
+    }
   }
   GSAJ_HIP_CHECK(hipGetLastError());
   return GSAJ_OK;

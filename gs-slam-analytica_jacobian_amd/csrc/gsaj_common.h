@@ -39,6 +39,8 @@ struct GeomWS {  // per-Gaussian state (reference: GeometryState, rasterizer_imp
   int *internal_radii;      // [P]
   uint32_t *block_sums;     // [nblk] per-workgroup totals, then exclusive offsets
   float *tau_partials;      // [nblk*8] per-workgroup dL/dtau partial sums
+  float4 *splat;            // [P*3] packed per-Gaussian row the tile sort gathers with three 16-B loads:
+                            //   (mean2D.x, mean2D.y, rect x0|y0<<10|w<<20, first emission slot) (conic, opacity) (rgb, -)
 };
 
 static inline __host__ __device__ size_t geom_carve(char *base, size_t P, GeomWS *g) {
@@ -61,6 +63,7 @@ static inline __host__ __device__ size_t geom_carve(char *base, size_t P, GeomWS
   CARVE(internal_radii, int, P);
   CARVE(block_sums, uint32_t, nblk);
   CARVE(tau_partials, float, ((P + GB_BLOCK - 1) / GB_BLOCK + 1) * 8);
+  CARVE(splat, float4, P * 3);
   return off;
 }
 
@@ -68,6 +71,7 @@ static inline __host__ __device__ size_t geom_carve(char *base, size_t P, GeomWS
 #define LDS_TILES_MAX 8192  // images with more tiles than this bin with direct global atomics
 #define SORT_CAP 4096     // largest tile list the in-LDS tile sort handles; longer lists -> global radix fallback
 #define N_COUNTERS 64     // frame counters: [0] num_rendered [1] error flags [2] longest tile list [3] tau ticket
+                          //   [5] preprocess ticket (last workgroup runs the frame scan)
                           //   [4] abort (async forward: arena too small / tile list too long -> later kernels return)
 #define ERR_PREFILTERED 1u
 #define ERR_INTERNAL 2u

@@ -102,6 +102,8 @@ __device__ __forceinline__ float3 sh_to_rgb(int deg, float3 pos, float3 campos, 
   return make_float3(out[0], out[1], out[2]);
 }
 
+__device__ void frame_scan(int nblk, int tiles, int capacity, uint32_t *block_sums, ImageWS im);
+
 __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__restrict__ radii, int *__restrict__ n_touched,
                                                          GeomWS g, ImageWS im) {
   __shared__ uint32_t scan[PRE_BLOCK];
@@ -117,6 +119,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__re
   uint32_t touched = 0;
   if (idx < p.P) {
     int my_radius_i = 0;
+    uint32_t rect_pack = 0;
     float2 xy = make_float2(0.f, 0.f);
     float depth = 0.f;
     float4 con_o = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -158,6 +161,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__re
             const float3 cam = make_float3(p.campos[0], p.campos[1], p.campos[2]);
             rgb = sh_to_rgb(p.D, p_orig, cam, p.shs + (size_t)idx * p.M * 3, cl);
           }
+          rect_pack = (uint32_t)x0 | ((uint32_t)y0 << 10) | ((uint32_t)(x1 - x0) << 20);
           depth = p_view.z;
           my_radius_i = (int)my_radius;
           xy = pim;
@@ -187,6 +191,10 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__re
       g.clamped[3 * (size_t)idx] = cl[0]; g.clamped[3 * (size_t)idx + 1] = cl[1]; g.clamped[3 * (size_t)idx + 2] = cl[2];
     }
     g.tiles_touched[idx] = touched;
+    if (p.colors_precomp) rgb = ld3(p.colors_precomp, idx);
+    g.splat[3 * (size_t)idx + 0] = make_float4(xy.x, xy.y, __uint_as_float(rect_pack), 0.f);
+    g.splat[3 * (size_t)idx + 1] = con_o;
+    g.splat[3 * (size_t)idx + 2] = make_float4(rgb.x, rgb.y, rgb.z, 0.f);
   }
   // block-local inclusive scan of tiles_touched (Hillis-Steele over 256 lanes)
   scan[tid] = touched;
@@ -204,38 +212,60 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__re
     __syncthreads();
   }
   if (idx < p.P) g.point_offsets[idx] = scan[tid];
-  if (tid == PRE_BLOCK - 1) g.block_sums[blockIdx.x] = scan[tid];
+  if (tid == PRE_BLOCK - 1)  // write-through (sc1): read by the last workgroup below
+    __hip_atomic_store(&g.block_sums[blockIdx.x], scan[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // ---- the last workgroup to arrive scans the per-workgroup totals and the tile histogram ----
+  // hand-off (counter form): every wave drains its histogram atomics / sc1 store, the workgroup
+  // meets at a barrier, one lane draws a relaxed agent-scope ticket; the last arriver reads the
+  // other workgroups' data with sc1 loads only.
+  __shared__ uint32_t s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0)
+    s_last = __hip_atomic_fetch_add(&im.counters[5], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  __syncthreads();
+  if (s_last) frame_scan((int)gridDim.x, tiles, p.capacity, g.block_sums, im);
 }
 
-// Single-workgroup exclusive scan of n items: each lane sums a contiguous run, the 1024 run totals
-// are scanned with wave shuffles + one LDS hop, then each lane rewrites its run.  Returns the total.
-__device__ uint32_t block_exclusive_scan(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, int n,
-                                         uint32_t *__restrict__ run_max) {
-  __shared__ uint32_t wsum[16];
+// Exclusive scan of n items by ONE workgroup of PRE_BLOCK lanes: each lane sums a contiguous run, the
+// run totals are scanned with wave shuffles + one LDS hop, then each lane rewrites its run.  Inputs
+// were produced by OTHER workgroups of the same launch (sc1 stores / L2 atomics), so they are read
+// with sc1 (L1-bypassing) loads.  Returns the total.
+__device__ uint32_t tail_exclusive_scan(const uint32_t *in, uint32_t *out, int n, uint32_t *run_max) {
+  __shared__ uint32_t wsum[PRE_BLOCK / 64];
+  __shared__ uint32_t wmax[PRE_BLOCK / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int per = (n + 1023) / 1024;
+  const int per = (n + PRE_BLOCK - 1) / PRE_BLOCK;
   const int b0 = min(n, tid * per), b1 = min(n, b0 + per);
-  uint32_t s = 0;
-  for (int i = b0; i < b1; i++) s += in[i];
-  uint32_t incl = s;  // inclusive scan of s over the 1024 lanes
+  uint32_t s = 0, mx = 0;
+  for (int i = b0; i < b1; i++) {
+    const uint32_t v = __hip_atomic_load(&in[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s += v;
+    mx = max(mx, v);
+  }
+  uint32_t incl = s;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
     const uint32_t v = __shfl_up((int)incl, o);
     if (lane >= o) incl += v;
   }
-  if (lane == 63) wsum[wave] = incl;
-  __syncthreads();
-  uint32_t woff = 0, total = 0;
 #pragma unroll
-  for (int w = 0; w < 16; w++) {
+  for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+  if (lane == 63) wsum[wave] = incl;
+  if (lane == 0) wmax[wave] = mx;
+  __syncthreads();
+  uint32_t woff = 0, total = 0, m = 0;
+#pragma unroll
+  for (int w = 0; w < PRE_BLOCK / 64; w++) {
     const uint32_t v = wsum[w];
     if (w < wave) woff += v;
     total += v;
+    m = max(m, wmax[w]);
   }
+  if (run_max) *run_max = m;
   uint32_t run = woff + incl - s;
-  (void)run_max;
   for (int i = b0; i < b1; i++) {
-    const uint32_t v = in[i];
+    const uint32_t v = __hip_atomic_load(&in[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     out[i] = run;
     run += v;
   }
@@ -243,29 +273,16 @@ __device__ uint32_t block_exclusive_scan(const uint32_t *__restrict__ in, uint32
   return total;
 }
 
-// One launch, one workgroup: (1) exclusive offsets of the per-workgroup Gaussian totals and the
-// grand total R; (2) exclusive offsets of the replicated per-tile histogram in tile-major order, so
-// a tile's list is the contiguous union of its replicas' segments; (3) the longest tile list.
-__global__ __launch_bounds__(1024) void k_scan(int nblk, int tiles, int capacity, uint32_t *__restrict__ block_sums,
-                                               ImageWS im) {
-  __shared__ uint32_t smax[16];
-  const int tid = threadIdx.x;
-  const uint32_t R = block_exclusive_scan(block_sums, block_sums, nblk, nullptr);
-  uint32_t mx = 0;
-  for (int t = tid; t < tiles; t += 1024) {
-    uint32_t c = 0;
-#pragma unroll
-    for (int r = 0; r < TILE_REP; r++) c += im.tile_count[t * TILE_REP + r];
-    mx = max(mx, c);
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
-  if ((tid & 63) == 0) smax[tid >> 6] = mx;
-  const uint32_t R2 = block_exclusive_scan(im.tile_count, im.tile_offset, tiles * TILE_REP, nullptr);
-  if (tid == 0) {
-    uint32_t m = 0;
-    for (int w = 0; w < 16; w++) m = max(m, smax[w]);
-    im.tile_offset[tiles * TILE_REP] = R2;
+// Run by the LAST workgroup of k_preprocess to arrive (replaces cub::DeviceScan of
+// rasterizer_impl.cu:327 and a separate launch): (1) exclusive offsets of the per-workgroup Gaussian
+// totals and the grand total R; (2) exclusive offsets of the per-tile histogram; (3) the longest
+// tile list; (4) for the async forward, the device-side capacity check.
+__device__ void frame_scan(int nblk, int tiles, int capacity, uint32_t *block_sums, ImageWS im) {
+  const uint32_t R = tail_exclusive_scan(block_sums, block_sums, nblk, nullptr);
+  uint32_t m = 0;
+  const uint32_t R2 = tail_exclusive_scan(im.tile_count, im.tile_offset, tiles, &m);
+  if (threadIdx.x == 0) {
+    im.tile_offset[tiles] = R2;
     im.counters[0] = R;
     im.counters[2] = m;
     uint32_t err = 0u;
@@ -304,7 +321,9 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scatter_instances(int P, int gx, 
   int r = 0, x0 = 0, y0 = 0, x1 = 0, y1 = 0;
   uint64_t key = 0;
   if (idx < P) {
-    g.point_offsets[idx] = g.block_sums[blockIdx.x] + g.point_offsets[idx];
+    const uint32_t incl = g.block_sums[blockIdx.x] + g.point_offsets[idx];
+    g.point_offsets[idx] = incl;
+    reinterpret_cast<float *>(g.splat)[12 * (size_t)idx + 3] = __uint_as_float(incl - g.tiles_touched[idx]);
     r = radii[idx];
     if (r > 0) {
       const float2 xy = g.means2D[idx];
@@ -323,9 +342,21 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scatter_instances(int P, int gx, 
   for (int y = y0; y < y1; y++)
     for (int x = x0; x < x1; x++) atomicAdd(&cnt[y * gx + x], 1u);
   __syncthreads();
-  for (int t = tid; t < tiles; t += PRE_BLOCK) {
-    const uint32_t c = cnt[t];
-    if (c) cnt[t] = im.tile_offset[t] + atomicAdd(&im.tile_cursor[t], c);  // this workgroup's slot range in tile t
+  // reserve this workgroup's slot range in every tile it touches: returning atomics, issued eight at
+  // a time so their round trips overlap (one s_waitcnt per batch instead of one per tile)
+  for (int t0 = 0; t0 < tiles; t0 += 8 * PRE_BLOCK) {
+    uint32_t c[8], base[8];
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+      const int t = t0 + b * PRE_BLOCK + tid;
+      c[b] = t < tiles ? cnt[t] : 0u;
+      base[b] = c[b] ? atomicAdd(&im.tile_cursor[t], c[b]) : 0u;
+    }
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+      const int t = t0 + b * PRE_BLOCK + tid;
+      if (c[b]) cnt[t] = im.tile_offset[t] + base[b];
+    }
   }
   __syncthreads();
   for (int y = y0; y < y1; y++)
@@ -392,14 +423,13 @@ __global__ __launch_bounds__(256) void k_tile_sort_records(int gx, int gy, const
     const uint32_t id = (uint32_t)key;
     const uint32_t k = beg + (uint32_t)i;
     point_list[k] = id;
-    const float2 xy = g.means2D[id];
-    records[(size_t)k * REC_F4 + 0] = make_float4(xy.x, xy.y, __uint_as_float((uint32_t)(key >> 32)), __uint_as_float(id));
-    records[(size_t)k * REC_F4 + 1] = g.conic_opacity[id];
-    int x0, y0, x1, y1;
-    tile_rect(xy.x, xy.y, radii[id], gx, gy, x0, y0, x1, y1);
-    const uint32_t u = g.point_offsets[id] - g.tiles_touched[id] + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
-    records[(size_t)k * REC_F4 + 2] = make_float4(features[3 * (size_t)id], features[3 * (size_t)id + 1],
-                                                  features[3 * (size_t)id + 2], __uint_as_float(u));
+    const float4 a = g.splat[3 * (size_t)id + 0], bq = g.splat[3 * (size_t)id + 1], c = g.splat[3 * (size_t)id + 2];
+    const uint32_t rp = __float_as_uint(a.z);
+    const int x0 = (int)(rp & 1023u), y0 = (int)((rp >> 10) & 1023u), w = (int)(rp >> 20);
+    const uint32_t u = __float_as_uint(a.w) + (uint32_t)((ty - y0) * w + (tx - x0));
+    records[(size_t)k * REC_F4 + 0] = make_float4(a.x, a.y, __uint_as_float((uint32_t)(key >> 32)), __uint_as_float(id));
+    records[(size_t)k * REC_F4 + 1] = bq;
+    records[(size_t)k * REC_F4 + 2] = make_float4(c.x, c.y, c.z, __uint_as_float(u));
   }
 }
 
@@ -443,10 +473,6 @@ int launch_preprocess(const FwdParams &p, int *radii, int *n_touched, const Geom
     const int tiles = p.grid_x * p.grid_y;
     const size_t lds = tiles <= LDS_TILES_MAX ? sizeof(uint32_t) * (size_t)tiles : 0;
     hipLaunchKernelGGL(k_preprocess, dim3(nblk), dim3(PRE_BLOCK), lds, s, p, radii, n_touched, g, im);
-  }
-  {
-    GsajProfScope ps(ST_SCAN, s);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, nblk, p.grid_x * p.grid_y, p.capacity, g.block_sums, im);
   }
   GSAJ_HIP_CHECK(hipGetLastError());
   return GSAJ_OK;
