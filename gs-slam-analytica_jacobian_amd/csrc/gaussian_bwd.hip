@@ -189,6 +189,12 @@ __global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g
       __syncthreads();
     }
   }
+  // every output of this Gaussian stays in registers until the dL/dtau hand-off below has been made:
+  // the hand-off drains this wave's outstanding stores (s_waitcnt vmcnt(0)), so the bulk stores come last
+  float o_m2x = 0.f, o_m2y = 0.f, o_ca = 0.f, o_cb = 0.f, o_cc = 0.f, o_op = 0.f, o_dz = 0.f;
+  float3 o_col = make_float3(0.f, 0.f, 0.f), o_gm = make_float3(0.f, 0.f, 0.f), o_scale = make_float3(0.f, 0.f, 0.f);
+  float4 o_rot = make_float4(0.f, 0.f, 0.f, 0.f);
+  float o_cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (vis) {
     const float g2x = s0.x, g2y = s0.y;           // dL/dmean2D (NDC-scaled)
     const float gcx = s0.z, gcy = s0.w, gcz = s1.x;  // dL/dconic a, b, c
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g
       gcov[4] = 2 * M[0][2] * M[0][1] * dL_da + (M[0][1] * M[1][2] + M[0][2] * M[1][1]) * dL_db + 2 * M[1][1] * M[1][2] * dL_dc;
     }
 #pragma unroll
-    for (int k = 0; k < 6; k++) p.dL_dcov3D[6 * (size_t)idx + k] = gcov[k];
+    for (int k = 0; k < 6; k++) o_cov[k] = gcov[k];
     float dM[2][3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -308,13 +314,7 @@ __global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g
       gm.x += dmean.x; gm.y += dmean.y; gm.z += dmean.z;
       tau[0] -= dmean.x; tau[1] -= dmean.y; tau[2] -= dmean.z;
     }
-    p.dL_dmean2D[3 * (size_t)idx] = g2x; p.dL_dmean2D[3 * (size_t)idx + 1] = g2y; p.dL_dmean2D[3 * (size_t)idx + 2] = 0.f;
-    p.dL_dconic[4 * (size_t)idx] = gcx; p.dL_dconic[4 * (size_t)idx + 1] = gcy; p.dL_dconic[4 * (size_t)idx + 2] = 0.f;
-    p.dL_dconic[4 * (size_t)idx + 3] = gcz;
-    p.dL_dopacity[idx] = gop;
-    p.dL_dcolor[3 * (size_t)idx] = gcol.x; p.dL_dcolor[3 * (size_t)idx + 1] = gcol.y; p.dL_dcolor[3 * (size_t)idx + 2] = gcol.z;
-    p.dL_ddepth[idx] = gz;
-    p.dL_dmean3D[3 * (size_t)idx] = gm.x; p.dL_dmean3D[3 * (size_t)idx + 1] = gm.y; p.dL_dmean3D[3 * (size_t)idx + 2] = gm.z;
+    o_m2x = g2x; o_m2y = g2y; o_ca = gcx; o_cb = gcy; o_cc = gcz; o_op = gop; o_col = gcol; o_dz = gz; o_gm = gm;
     // ---- 6. cov3D -> scale, rotation ----
     if (p.scales) {
       const float r = q.x, x = q.y, y = q.z, z = q.w;
@@ -331,8 +331,9 @@ __global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g
 #pragma unroll
         for (int cc = 0; cc < 3; cc++)
           dA[i][cc] = 2.0f * ((s[i] * R[0][i]) * dS[0][cc] + (s[i] * R[1][i]) * dS[1][cc] + (s[i] * R[2][i]) * dS[2][cc]);
-#pragma unroll
-      for (int k = 0; k < 3; k++) p.dL_dscale[3 * (size_t)idx + k] = R[0][k] * dA[k][0] + R[1][k] * dA[k][1] + R[2][k] * dA[k][2];
+      o_scale.x = R[0][0] * dA[0][0] + R[1][0] * dA[0][1] + R[2][0] * dA[0][2];
+      o_scale.y = R[0][1] * dA[1][0] + R[1][1] * dA[1][1] + R[2][1] * dA[1][2];
+      o_scale.z = R[0][2] * dA[2][0] + R[1][2] * dA[2][1] + R[2][2] * dA[2][2];
       float gR[3][3];  // dL/dR[j][i] = s_i dA[i][j]
 #pragma unroll
       for (int i = 0; i < 3; i++)
@@ -343,45 +344,10 @@ __global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g
       dq.y = 2 * y * (gR[0][1] + gR[1][0]) + 2 * z * (gR[0][2] + gR[2][0]) + 2 * r * (gR[2][1] - gR[1][2]) - 4 * x * (gR[2][2] + gR[1][1]);
       dq.z = 2 * x * (gR[0][1] + gR[1][0]) + 2 * r * (gR[0][2] - gR[2][0]) + 2 * z * (gR[2][1] + gR[1][2]) - 4 * y * (gR[2][2] + gR[0][0]);
       dq.w = 2 * r * (gR[1][0] - gR[0][1]) + 2 * x * (gR[0][2] + gR[2][0]) + 2 * y * (gR[2][1] + gR[1][2]) - 4 * z * (gR[1][1] + gR[0][0]);
-      reinterpret_cast<float4 *>(p.dL_drot)[idx] = dq;
-    }
-    if (p.dL_dtau) {
-#pragma unroll
-      for (int k = 0; k < 6; k++) p.dL_dtau[6 * (size_t)idx + k] = tau[k];
-    }
-  } else if (idx < p.P) {
-    // culled Gaussian: its rows are zero (the reference's binding memsets every output first)
-    const size_t i = (size_t)idx;
-#pragma unroll
-    for (int k = 0; k < 3; k++) { p.dL_dmean2D[3 * i + k] = 0.f; p.dL_dcolor[3 * i + k] = 0.f; p.dL_dmean3D[3 * i + k] = 0.f; }
-#pragma unroll
-    for (int k = 0; k < 4; k++) p.dL_dconic[4 * i + k] = 0.f;
-    p.dL_dopacity[i] = 0.f;
-    p.dL_ddepth[i] = 0.f;
-#pragma unroll
-    for (int k = 0; k < 6; k++) p.dL_dcov3D[6 * i + k] = 0.f;
-    if (p.scales) {
-#pragma unroll
-      for (int k = 0; k < 3; k++) p.dL_dscale[3 * i + k] = 0.f;
-      reinterpret_cast<float4 *>(p.dL_drot)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    if (p.dL_dtau) {
-#pragma unroll
-      for (int k = 0; k < 6; k++) p.dL_dtau[6 * i + k] = 0.f;
+      o_rot = dq;
     }
   }
-  // ---- 7. dL/dSH block: coalesced store (rows of culled Gaussians and coefficients above the active
-  //         degree are zero) ----
-  if (p.shs) {
-    __syncthreads();
-    const size_t base = (size_t)blockIdx.x * GB_BLOCK * shw;
-    const int count = min(GB_BLOCK, p.P - blockIdx.x * GB_BLOCK) * shw;
-    for (int e = tid; e < count; e += GB_BLOCK) {
-      const int gi = e / shw, k = e - gi * shw;
-      p.dL_dsh[base + e] = sh_out[gi * shs_stride + k];
-    }
-  }
-  // ---- 8. wave partial of dL/dtau (fixed butterfly) ----
+  // ---- 7. wave partial of dL/dtau (fixed butterfly) ----
 #pragma unroll
   for (int k = 0; k < 6; k++) {
     float v = tau[k];
@@ -390,8 +356,8 @@ __global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g
     if (tid == 0)  // write-through (sc1) store: part of the fence-free hand-off below
       __hip_atomic_store(&g.tau_partials[(size_t)blockIdx.x * 8 + k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (!p.dL_dtau_sum) return;
-  // ---- 9. the last workgroup to arrive sums the partials in workgroup order (fp64): deterministic,
+  if (p.dL_dtau_sum) {
+  // ---- 8. the last workgroup to arrive sums the partials in workgroup order (fp64): deterministic,
   // no extra launch (replaces torch.sum over [P,6], diff_gaussian_rasterization/__init__.py:162).
   // Hand-off without fences (MI355X_MICROARCH.md, hand-offs measured with sc1 loads in place of the
   // acquire): the 6 partials are stored write-through (sc1) by lane 0, drained with vmcnt(0), then
@@ -403,7 +369,7 @@ __global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g
     s_ticket = __hip_atomic_fetch_add(&counters[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
-  if (s_ticket != gridDim.x - 1) return;
+  if (s_ticket == gridDim.x - 1) {
   const int nblk = (int)gridDim.x;
   double acc6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   for (int i = tid; i < nblk; i += GB_BLOCK) {  // rows are independent loads: all in flight at once
@@ -419,6 +385,38 @@ __global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g
     if (tid == 0) p.dL_dtau_sum[k] = (float)v;
   }
   if (tid == 0) counters[3] = 0u;  // ready for the next backward over this workspace
+  }
+  }
+  // ---- 9. outputs: one row per Gaussian, zeros for culled ones (the reference's binding memsets first) ----
+  if (idx < p.P) {
+    const size_t i = (size_t)idx;
+    p.dL_dmean2D[3 * i] = o_m2x; p.dL_dmean2D[3 * i + 1] = o_m2y; p.dL_dmean2D[3 * i + 2] = 0.f;
+    reinterpret_cast<float4 *>(p.dL_dconic)[i] = make_float4(o_ca, o_cb, 0.f, o_cc);
+    p.dL_dopacity[i] = o_op;
+    p.dL_dcolor[3 * i] = o_col.x; p.dL_dcolor[3 * i + 1] = o_col.y; p.dL_dcolor[3 * i + 2] = o_col.z;
+    p.dL_ddepth[i] = o_dz;
+    p.dL_dmean3D[3 * i] = o_gm.x; p.dL_dmean3D[3 * i + 1] = o_gm.y; p.dL_dmean3D[3 * i + 2] = o_gm.z;
+#pragma unroll
+    for (int k = 0; k < 6; k++) p.dL_dcov3D[6 * i + k] = o_cov[k];
+    if (p.scales) {
+      p.dL_dscale[3 * i] = o_scale.x; p.dL_dscale[3 * i + 1] = o_scale.y; p.dL_dscale[3 * i + 2] = o_scale.z;
+      reinterpret_cast<float4 *>(p.dL_drot)[i] = o_rot;
+    }
+    if (p.dL_dtau) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) p.dL_dtau[6 * i + k] = tau[k];
+    }
+  }
+  // dL/dSH block: coalesced store (rows of culled Gaussians and coefficients above the active degree are zero)
+  if (p.shs) {
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * GB_BLOCK * shw;
+    const int count = min(GB_BLOCK, p.P - blockIdx.x * GB_BLOCK) * shw;
+    for (int e = tid; e < count; e += GB_BLOCK) {
+      const int gi = e / shw, k = e - gi * shw;
+      p.dL_dsh[base + e] = sh_out[gi * shs_stride + k];
+    }
+  }
 }
 
 int launch_gaussian_backward(const BwdParams &p, const GeomWS &g, const BinWS &b, const ImageWS &im, hipStream_t s) {
