@@ -5,23 +5,35 @@
 // each pixel's last contributor, T <- T/(1-alpha), recurrences accum_rec / accum_rec_depth,
 // dL/dalpha incl. the background term, dL/dmean2D scaled by (W/2, H/2).
 //
-// MI355X design (differs from the reference on purpose):
-//  * the reference reduces the 10 per-pixel partials of EVERY list entry with a 256-thread
-//    shared-memory tree (8 barrier rounds, backward.cu:633-644) and then issues 10 global float
-//    atomics.  Here each wave64 (an 8x8 pixel quadrant) reduces its 10 partials in registers:
-//    v_permlane32_swap / v_permlane16_swap merge two registers per instruction across the
-//    half-wave and row boundaries (10 -> 5 -> 3 registers), then four DPP row rotations finish
-//    the 16-lane rows.  ~29 VALU ops per entry, no barrier, no LDS traffic for the reduction.
-//  * no global atomics at all: the four waves of a tile write their totals to private LDS slots,
-//    and after each round of BWD_ROUND entries the workgroup stores one 48-byte partial-gradient
-//    row per (tile, Gaussian) instance, coalesced, at the instance's sorted position.  The
-//    per-Gaussian kernel (gaussian_bwd.hip) sums a Gaussian's instances in a fixed order, so
-//    gradients are bit-reproducible run to run (the reference's float atomics are not).
-//  * entries beyond the quadrant's / tile's furthest last-contributor are never visited.
+// MI355X design (differs from the reference on purpose).  The reference reduces the 10 per-pixel
+// partials of EVERY list entry with a 256-thread shared-memory tree (8 barrier rounds,
+// backward.cu:633-644) and then issues 10 global float atomics.  Here a wave64 owns an 8x8 pixel
+// quadrant and works in two phases per batch of 8 accepted entries:
+//
+//  phase 1 (lane = pixel):  the sequential part only.  For an entry the quadrant can see
+//    (lane-parallel culling, see wave_reduce.h) each lane advances T and accum_rec and produces
+//    just TWO scalars: w = dL/dG * G and u = alpha * T.  All 10 partials are linear in (w, u):
+//      d/dmean2D ~ w * (conic . d),  d/dconic ~ w * d d^T,  d/dopacity = w / o,  d/dcolour = u * dL/dC,
+//      d/ddepth = u * dL/dD.        (w, u) go to LDS, one 64-pixel row per entry.
+//  phase 2 (lane = (entry slot, pixel row)):  8 slots x 8 pixel rows = 64 lanes.  Each lane walks
+//    the 8 pixels of its row, accumulating the 6 moments of w (1, dx, dy, dx^2, dx dy, dy^2) and
+//    the 4 products u * seed; the 8 rows of a slot are then combined with three register-merge
+//    steps (v_permlane32_swap, v_permlane16_swap, one DPP rotation).  ~21 plain VALU per entry,
+//    against ~29 cross-lane instructions (~80 plain-VALU issue slots, measured) for reducing the 10
+//    partials of every entry across the wave directly.
+//
+//  No global atomics: the four waves of a tile write per-entry totals to private LDS slots, and
+//  after each round the workgroup stores one 48-byte partial-gradient row per (tile, Gaussian)
+//  instance at the instance's emission slot.  The per-Gaussian kernel (gaussian_bwd.hip) sums a
+//  Gaussian's rows in a fixed order, so gradients are bit-reproducible run to run (the reference's
+//  float atomics are not).  Entries beyond the quadrant's / tile's furthest last-contributor are
+//  never visited.
 #include "gsaj_common.h"
 #include "wave_reduce.h"
 
-#define BWD_ROUND 128
+#define BWD_ROUND 64   // list entries staged per workgroup round
+#define SLOTS 8        // accepted entries per phase-2 batch
+#define WU_STRIDE 65   // float2 per slot row (64 pixels + 1: conflict-free ds_read_b64 in phase 2)
 
 __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int gx, const uint2 *__restrict__ ranges,
                                                     const float4 *__restrict__ records, const float *__restrict__ bg,
@@ -32,10 +44,14 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int gx, const 
                                                     float4 *__restrict__ inst_grad,
                                                     const uint32_t *__restrict__ counters) {
   __shared__ float4 rec[BWD_ROUND * REC_F4];
-  if (counters[4]) return;  // aborted async frame
-  __shared__ float acc[BWD_ROUND * 4 * IGRAD_F];  // [entry][wave][12]
+  __shared__ float acc[BWD_ROUND * 4 * IGRAD_F];      // [entry][wave][12]
+  __shared__ float2 wu_all[4 * SLOTS * WU_STRIDE];     // [wave][slot][pixel] (w, u)
+  __shared__ float4 seed_all[4 * 64];                  // [wave][pixel] (dL/dC rgb, dL/dD)
   __shared__ uint32_t wave_max[4];
+  if (counters[4]) return;  // aborted async frame
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  float2 *wu = wu_all + wave * SLOTS * WU_STRIDE;
+  float4 *seed = seed_all + wave * 64;
   const int tile = blockIdx.x;
   const int ty = tile / gx, tx = tile - ty * gx;
   const int px = tx * TILE + (wave & 1) * 8 + (lane & 7);
@@ -56,6 +72,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int gx, const 
     gC2 = dL_dpix[2 * HW + pid];
     gD = dL_dpix_depth[pid];
   }
+  seed[lane] = make_float4(gC0, gC1, gC2, gD);
   const float bg_dot = bg[0] * gC0 + bg[1] * gC1 + bg[2] * gC2;
   const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
 
@@ -68,6 +85,10 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int gx, const 
   const uint32_t bmax = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
 
   float accC0 = 0.f, accC1 = 0.f, accC2 = 0.f, accD = 0.f;  // accum_rec, accum_rec_depth
+
+  // phase-2 lane roles
+  const int p2_slot = lane & (SLOTS - 1), p2_row = lane >> 3;
+  const float p2_py = qy0 + (float)p2_row;
 
   uint32_t hi = range.x + bmax;  // exclusive sorted position
   // entries [hi, range.y) were never reached by any pixel of the tile: their partials are zero
@@ -95,78 +116,120 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int gx, const 
 
     const uint32_t first_idx = lo - range.x;  // list index (0-based) of rec[0]
     if (wmax > first_idx) {
-      for (int jb = ((n - 1) >> 6) << 6; jb >= 0; jb -= 64) {
-        // lane l tests entry jb+l against this wave's quadrant (and its furthest last contributor);
-        // the loop then visits only the set bits, back to front
-        bool rel = false;
-        if (jb + lane < n && first_idx + (uint32_t)(jb + lane) < wmax) {
-          const float4 q0 = rec[(jb + lane) * REC_F4 + 0];
-          const float4 q1 = rec[(jb + lane) * REC_F4 + 1];
-          rel = quadrant_relevant(q0.x, q0.y, q1.x, q1.y, q1.z, q1.w, qx0, qy0);
+      // lane l tests entry l against this wave's quadrant (and its furthest last contributor)
+      bool rel = false;
+      if (lane < n && first_idx + (uint32_t)lane < wmax) {
+        const float4 q0 = rec[lane * REC_F4 + 0];
+        const float4 q1 = rec[lane * REC_F4 + 1];
+        rel = quadrant_relevant(q0.x, q0.y, q1.x, q1.y, q1.z, q1.w, qx0, qy0);
+      }
+      unsigned long long todo = __builtin_amdgcn_ballot_w64(rel);
+      int nslot = 0;      // accepted entries waiting in wu[] (wave-uniform)
+      int slot_entry = 0;  // lane s (< SLOTS): round-local index j of the entry in slot s
+
+      // ---- phase 2: moments of the queued (w, u) rows -> per-entry totals in this wave's acc slots ----
+      auto flush = [&]() {
+        const int j = __shfl(slot_entry, p2_slot);
+        const bool live = p2_slot < nslot;
+        const float4 e0 = rec[(live ? j : 0) * REC_F4 + 0];
+        const float4 e1 = rec[(live ? j : 0) * REC_F4 + 1];
+        const float dy = e0.y - p2_py;
+        float m0 = 0.f, mx = 0.f, my = 0.f, mxx = 0.f, mxy = 0.f, myy = 0.f, u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f;
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+          const int pix = p2_row * 8 + it;
+          const float2 q = wu[p2_slot * WU_STRIDE + pix];
+          const float4 sd = seed[pix];
+          const float dx = e0.x - (qx0 + (float)it);
+          const float wdx = q.x * dx, wdy = q.x * dy;
+          m0 += q.x;
+          mx += wdx;
+          my += wdy;
+          mxx += wdx * dx;
+          mxy += wdx * dy;
+          myy += wdy * dy;
+          u0 += q.y * sd.x;
+          u1 += q.y * sd.y;
+          u2 += q.y * sd.z;
+          u3 += q.y * sd.w;
         }
-        unsigned long long todo = __builtin_amdgcn_ballot_w64(rel);
-        if (todo == 0ull) continue;
-        // software pipeline: the record of the NEXT relevant entry is requested from LDS before the
-        // current one is processed, so its ~100-cycle read latency hides under ~90 VALU instructions
+        // the 10 partials are linear in the moments: convert per pixel row, then combine the 8 rows
+        float v[10];
+        v[0] = -(e1.x * mx + e1.y * my) * ddelx_dx;  // dL/dmean2D.x  (dG/ddx = -G (a dx + b dy))
+        v[1] = -(e1.z * my + e1.y * mx) * ddely_dy;  // dL/dmean2D.y
+        v[2] = -0.5f * mxx;                          // dL/dconic a
+        v[3] = -0.5f * mxy;                          // dL/dconic b
+        v[4] = -0.5f * myy;                          // dL/dconic c
+        v[5] = m0 * __builtin_amdgcn_rcpf(e1.w);     // dL/dopacity = sum G dL/dalpha = sum w / o
+        v[6] = u0; v[7] = u1; v[8] = u2; v[9] = u3;  // dL/dcolour, dL/ddepth
+        if (!live) {
+#pragma unroll
+          for (int c = 0; c < 10; c++) v[c] = 0.f;
+        }
+        const float w0 = merge32(v[0], v[1]), w1 = merge32(v[2], v[3]), w2 = merge32(v[4], v[5]), w3 = merge32(v[6], v[7]),
+                    w4 = merge32(v[8], v[9]);
+        float x0 = merge16(w0, w1), x1 = merge16(w2, w3), x2 = merge16(w4, w4);
+        x0 = dpp_add<0x128>(x0);  // row_ror:8: the two pixel rows that share a 16-lane row
+        x1 = dpp_add<0x128>(x1);
+        x2 = dpp_add<0x128>(x2);
+        // 16-lane row r = lane>>4 now holds, for slot lane&7: x0 -> v[{0,2,1,3}[r]], x1 -> v[{4,6,5,7}[r]], x2 -> v[{8,8,9,9}[r]]
+        if (live && (lane & 8) == 0) {
+          const int r = lane >> 4;
+          const int k = ((r & 1) << 1) | (r >> 1);
+          float *a = acc + (j * 4 + wave) * IGRAD_F;
+          a[k] = x0;
+          a[4 + k] = x1;
+          if ((r & 1) == 0) a[8 + (r >> 1)] = x2;
+        }
+        nslot = 0;
+      };
+
+      // ---- phase 1: back-to-front walk over the entries this quadrant can see ----
+      if (todo != 0ull) {
         int jj = 63 - __builtin_clzll(todo);
         todo &= ~(1ull << jj);
-        float4 n0 = rec[(jb + jj) * REC_F4 + 0], n1 = rec[(jb + jj) * REC_F4 + 1], n2 = rec[(jb + jj) * REC_F4 + 2];
+        float4 n0 = rec[jj * REC_F4 + 0], n1 = rec[jj * REC_F4 + 1], n2 = rec[jj * REC_F4 + 2];
         while (true) {
-          const int j = jb + jj;
+          const int j = jj;
           const uint32_t idx = first_idx + (uint32_t)j;
           const float4 r0 = n0, r1 = n1, r2 = n2;
           const bool more = todo != 0ull;
-          if (more) {
+          if (more) {  // software pipeline: request the next record before working on this one
             jj = 63 - __builtin_clzll(todo);
             todo &= ~(1ull << jj);
-            n0 = rec[(jb + jj) * REC_F4 + 0];
-            n1 = rec[(jb + jj) * REC_F4 + 1];
-            n2 = rec[(jb + jj) * REC_F4 + 2];
+            n0 = rec[jj * REC_F4 + 0];
+            n1 = rec[jj * REC_F4 + 1];
+            n2 = rec[jj * REC_F4 + 2];
           }
-        const float dx = r0.x - pxf, dy = r0.y - pyf;
-        const float power = -0.5f * (r1.x * dx * dx + r1.z * dy * dy) - r1.y * dx * dy;
-        const float G0 = __expf(power);
-        const float alpha0 = fminf(0.99f, r1.w * G0);
-        const bool valid = idx < last && power <= 0.0f && alpha0 >= (1.0f / 255.0f);
-        if (__builtin_amdgcn_ballot_w64(valid) != 0ull) {
-        // A lane that skips this entry runs the same arithmetic with alpha = G = 0: T, accum_rec and
-        // every partial then come out unchanged / zero, so two selects replace ~20 predicated updates.
-        const float alpha = valid ? alpha0 : 0.f;
-        const float G = valid ? G0 : 0.f;
-        const float inv1ma = __builtin_amdgcn_rcpf(1.f - alpha);
-        T = T * inv1ma;  // T <- T / (1 - alpha)
-        const float dchannel = alpha * T;
-        float dL_dalpha = (r2.x - accC0) * gC0 + (r2.y - accC1) * gC1 + (r2.z - accC2) * gC2 + (r0.z - accD) * gD;
-        dL_dalpha = dL_dalpha * T - (T_final * inv1ma) * bg_dot;
-        // accum_rec for the next (nearer) entry: alpha c + (1 - alpha) accum_rec  (backward.cu:799,811,
-        // applied here instead of lazily at the top of the next iteration -- same arithmetic)
-        const float oma = 1.f - alpha;
-        accC0 = alpha * r2.x + oma * accC0;
-        accC1 = alpha * r2.y + oma * accC1;
-        accC2 = alpha * r2.z + oma * accC2;
-        accD = alpha * r0.z + oma * accD;
-        const float dL_dG = r1.w * dL_dalpha;
-        const float gdx = G * dx, gdy = G * dy;
-        const float dG_ddelx = -gdx * r1.x - gdy * r1.y;
-        const float dG_ddely = -gdy * r1.z - gdx * r1.y;
-        float v[10];
-        v[0] = dL_dG * dG_ddelx * ddelx_dx;
-        v[1] = dL_dG * dG_ddely * ddely_dy;
-        v[2] = -0.5f * gdx * dx * dL_dG;
-        v[3] = -0.5f * gdx * dy * dL_dG;
-        v[4] = -0.5f * gdy * dy * dL_dG;
-        v[5] = G * dL_dalpha;
-        v[6] = dchannel * gC0;
-        v[7] = dchannel * gC1;
-        v[8] = dchannel * gC2;
-        v[9] = dchannel * gD;
-        // ---- wave reduction of the 10 partials (registers only), totals -> this wave's LDS slot ----
-        float x0, x1, x2;
-        reduce10(v, x0, x1, x2);
-        store10(acc + (j * 4 + wave) * IGRAD_F, lane, x0, x1, x2);
-        }
+          const float dx = r0.x - pxf, dy = r0.y - pyf;
+          const float power = -0.5f * (r1.x * dx * dx + r1.z * dy * dy) - r1.y * dx * dy;
+          const float G0 = __expf(power);
+          const float alpha0 = fminf(0.99f, r1.w * G0);
+          const bool valid = idx < last && power <= 0.0f && alpha0 >= (1.0f / 255.0f);
+          if (__builtin_amdgcn_ballot_w64(valid) != 0ull) {
+            // a lane that skips this entry runs the same arithmetic with alpha = G = 0: T and accum_rec
+            // come out unchanged and (w, u) = 0
+            const float alpha = valid ? alpha0 : 0.f;
+            const float G = valid ? G0 : 0.f;
+            const float inv1ma = __builtin_amdgcn_rcpf(1.f - alpha);
+            T = T * inv1ma;  // T <- T / (1 - alpha)
+            float dL_dalpha = (r2.x - accC0) * gC0 + (r2.y - accC1) * gC1 + (r2.z - accC2) * gC2 + (r0.z - accD) * gD;
+            dL_dalpha = dL_dalpha * T - (T_final * inv1ma) * bg_dot;
+            // accum_rec for the next (nearer) entry: alpha c + (1 - alpha) accum_rec (backward.cu:799,811,
+            // applied here instead of lazily at the top of the next iteration -- same arithmetic)
+            const float oma = 1.f - alpha;
+            accC0 = alpha * r2.x + oma * accC0;
+            accC1 = alpha * r2.y + oma * accC1;
+            accC2 = alpha * r2.z + oma * accC2;
+            accD = alpha * r0.z + oma * accD;
+            wu[nslot * WU_STRIDE + lane] = make_float2((r1.w * dL_dalpha) * G, alpha * T);
+            slot_entry = (lane == nslot) ? j : slot_entry;
+            nslot++;
+            if (nslot == SLOTS) flush();
+          }
           if (!more) break;
         }
+        if (nslot > 0) flush();
       }
     }
     __syncthreads();
@@ -197,7 +260,7 @@ int launch_render_backward(int R, int W, int H, int grid_x, int grid_y, const fl
   {
     GsajProfScope ps(ST_RENDER_BWD, s);
     hipLaunchKernelGGL(k_render_bwd, dim3(grid_x * grid_y), dim3(256), 0, s, W, H, grid_x, im.ranges, b.records, bg,
-                     im.final_T, im.n_contrib, dL_dpix, dL_dpix_depth, b.inst_grad, im.counters);
+                       im.final_T, im.n_contrib, dL_dpix, dL_dpix_depth, b.inst_grad, im.counters);
   }
   GSAJ_HIP_CHECK(hipGetLastError());
   return GSAJ_OK;
