@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync", action="store_true", help="read the instance count back on the host every frame")
+    ap.add_argument("--frames-in-flight", type=int, default=3,
+                    help="independent frames (keyframes of a mapping window) processed concurrently, one HIP stream each")
     ap.add_argument("--sh-coeffs", type=int, default=0, help="experiment: keep only the first N SH coefficients per Gaussian")
     return ap.parse_args()
 
@@ -90,34 +92,45 @@ def main():
     dLc = t(rng.normal(size=(3, H, W)) / (3 * H * W))  # pixel-gradient seeds, resident in HBM
     dLd = t(rng.normal(size=(1, H, W)) / (H * W))
     # two gradient buckets: the all-reduce of step i (RCCL stream) overlaps the kernels of step i+1
-    ctx = FrameContext(P, W, H, M, dev, grad_slots=2 if world > 1 else 1, n_keyframes=world if world > 1 else 0,
-                       keyframe=rank)
-    pending = [None, None]
-    counter = [0]
+    S = max(1, a.frames_in_flight)
+    ctxs = [FrameContext(P, W, H, M, dev, grad_slots=2 if world > 1 else 1, n_keyframes=world if world > 1 else 0,
+                         keyframe=rank) for _ in range(S)]
+    ctx = ctxs[0]
+    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(S - 1)]
+    pending = [[None, None] for _ in range(S)]
+    counter, seen = [0], [0] * S
 
-    def step():
-        slot = counter[0] & 1 if world > 1 else 0
+    def step(single=False):
+        k = 0 if single else counter[0] % S  # frame slot: its own workspaces, gradient buckets and HIP stream
+        n = seen[k]                 # how many frames this slot has processed
+        seen[k] += 1
         counter[0] += 1
-        if pending[slot] is not None:
-            pending[slot].wait()  # stream-level: the bucket is about to be overwritten
-            pending[slot] = None
-        # first frame: synchronous (sizes the binning arena); afterwards no host round trip per frame
-        ctx.forward(bg, means, opac, view, proj, campos, cam["tanfovx"], cam["tanfovy"], sh_degree=deg, shs=shs,
-                    scales=scales, rotations=rots, sync=(counter[0] == 1) or a.sync)
-        g = ctx.backward(bg, means, view, proj, proj_raw, campos, cam["tanfovx"], cam["tanfovy"], dLc, dLd,
-                         sh_degree=deg, shs=shs, scales=scales, rotations=rots, slot=slot)
-        if world > 1:  # one collective: per-Gaussian grads summed, per-keyframe dL/dtau gathered (bucket tail)
-            pending[slot] = ks.allreduce_gaussian_grads(ctx.buckets[slot], async_op=True)
+        slot = n & 1 if world > 1 else 0
+        c, pend = ctxs[k], pending[k]
+        with torch.cuda.stream(streams[k]):
+            if pend[slot] is not None:
+                pend[slot].wait()  # stream-level: the bucket is about to be overwritten
+                pend[slot] = None
+            # first frame: synchronous (sizes the binning arena); afterwards no host round trip per frame
+            c.forward(bg, means, opac, view, proj, campos, cam["tanfovx"], cam["tanfovy"], sh_degree=deg, shs=shs,
+                      scales=scales, rotations=rots, sync=(n == 0) or a.sync)
+            c.backward(bg, means, view, proj, proj_raw, campos, cam["tanfovx"], cam["tanfovy"], dLc, dLd,
+                       sh_degree=deg, shs=shs, scales=scales, rotations=rots, slot=slot)
+            if world > 1:  # one collective: per-Gaussian grads summed, per-keyframe dL/dtau gathered (bucket tail)
+                pend[slot] = ks.allreduce_gaussian_grads(c.buckets[slot], async_op=True)
 
     def fence():
-        for i in range(2):
-            if pending[i] is not None:
-                pending[i].wait()
-                pending[i] = None
+        for k in range(S):
+            with torch.cuda.stream(streams[k]):
+                for i in range(2):
+                    if pending[k][i] is not None:
+                        pending[k][i].wait()
+                        pending[k][i] = None
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    a.warmup = max(a.warmup, S)  # every frame slot sizes its binning arena on its first (synchronous) frame
     for _ in range(a.warmup):
         step()
     fence()
@@ -126,14 +139,23 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    R, _ = ctx.status()  # raises if any asynchronous frame was aborted on the device (arena too small)
+    for c in ctxs:
+        R, _ = c.status()  # raises if any asynchronous frame was aborted on the device (arena too small)
     inter = ctx.interactions()
 
-    # same K steps again with every kernel bracketed by HIP events on its launch stream
+    # the same K steps one frame at a time on one stream: per-frame latency as the tracker sees it
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step(single=True)
+    fence()
+    elapsed_single = time.perf_counter() - t0
+
+    # and once more with every kernel bracketed by HIP events on its launch stream
     fence()
     with profile_stages(max_records=a.steps * 16) as prof:
         for _ in range(a.steps):
-            step()
+            step(single=True)
     fence()
 
     stats = torch.tensor([elapsed, float(inter), float(R)], dtype=torch.float64, device=dev)
@@ -164,11 +186,14 @@ def main():
             "config": {"workload": "%s: %d Gaussians (SH degree %d, %d coeffs), %dx%d, forward splat + analytical "
                                    "Jacobian backward (dL/dmu, dL/dSigma->conic, per-Gaussian grads, dL/dtau)"
                                    % (a.workload, P, deg, M, W, H),
-                       "interactions_per_frame_rank0": inter, "num_rendered_rank0": R,
-                       "parallelism": "1 keyframe per GPU; ONE async all-reduce of a %d-float bucket (per-Gaussian grads + per-keyframe dL/dtau rows), overlapped with the next step"
-                                      % ctx.buckets[0].numel() if world > 1 else "single GPU"},
+                       "interactions_per_frame_rank0": inter, "num_rendered_rank0": R, "frames_in_flight": S,
+                       "parallelism": ("%d independent frames in flight per GPU, one HIP stream each; " % S) + "1 keyframe per GPU; ONE async all-reduce of a %d-float bucket (per-Gaussian grads + per-keyframe dL/dtau rows), overlapped with the next step"
+                                      % ctx.buckets[0].numel() if world > 1 else "single GPU; %d independent frames in flight, one HIP stream each" % S},
             "roofline": {"bound": "mfma", "kernel": "k_render_bwd", "achieved": ach, "peak": PEAK_FP32_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
+                         "traffic": pmc_traffic("k_render_bwd") if (a.workload == "cfg2" and M == 16) else None,
+                         "traffic_unit": "bytes/launch (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, "
+                                         "profiles/r01_pmc_hbm_fetch_write_kb.json; algorithmic: %d)" % (R * 96 + W * H * 32),
                          "note": "fp32 VALU/transcendental-bound reverse compositor: 87 fp32 flop x interactions per "
                                  "launch / HIP-event launch time; peak = fp32 vector = fp32 MFMA dense peak",
                          "avg_launch_ms": t_bwd * 1e3},
@@ -178,6 +203,8 @@ def main():
                 "k_gaussian_bwd": {"bound": "hbm", "achieved": gb_bytes / t_gb / 1e9 if t_gb > 0 else 0.0,
                                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "avg_launch_ms": t_gb * 1e3,
                                    "algorithmic_bytes": gb_bytes}},
+            "single_stream": {"ms_per_step": 1e3 * elapsed_single / a.steps, "value_rank0": inter * a.steps / elapsed_single,
+                              "note": "same K steps, one frame at a time on one HIP stream (sequential tracking iterations)"},
             "stage_ms_per_step": {k: v / a.steps for k, v in prof.ms.items() if prof.launches[k]},
         }
         for k in ("k_render_fwd", "k_gaussian_bwd"):
@@ -188,6 +215,20 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel):
+    """Memory-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes over this same
+    command (FETCH_SIZE and WRITE_SIZE, in KB, each collected in its own --pmc run; FETCH_SIZE doubled
+    for 16-B/lane streaming reads as MI355X_MICROARCH.md prescribes for gfx950).  None if the summary
+    is not in the tree: PMC counters cannot be read from inside the timed process."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_fetch_write_kb.json")
+    try:
+        with open(path) as f:
+            k = json.load(f)[kernel]
+        return (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(cam, sc, deg, budget_s):

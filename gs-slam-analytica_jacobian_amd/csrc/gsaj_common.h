@@ -218,3 +218,32 @@ __device__ __forceinline__ float3 cross3(float3 a, float3 b) {
   return make_float3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
 #endif
+
+// ---- optional per-wave schedule trace (build with -DGSAJ_BLOCK_TRACE; tools/block_trace.py) -----------------
+// Each traced kernel records, per wave: start and end of the 100 MHz wall clock, HW_ID and XCC_ID.
+#ifdef GSAJ_BLOCK_TRACE
+#define GSAJ_TRACE_MAX 65536
+#define GSAJ_TRACE_DEFINE(NAME)                                                                               \
+  __device__ unsigned long long g_trace_##NAME[4 * GSAJ_TRACE_MAX];                                           \
+  extern "C" int gsaj_trace_read_##NAME(unsigned long long *host, int nwaves) {                               \
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace_##NAME), sizeof(unsigned long long) * 4 * nwaves); \
+  }
+#define GSAJ_TRACE_BEGIN(NAME)                                                                                \
+  {                                                                                                           \
+    const unsigned tw_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                                 \
+    if ((threadIdx.x & 63) == 0 && tw_ < GSAJ_TRACE_MAX) {                                                    \
+      g_trace_##NAME[4 * tw_ + 0] = wall_clock64();                                                           \
+      g_trace_##NAME[4 * tw_ + 2] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));                   \
+      g_trace_##NAME[4 * tw_ + 3] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));                  \
+    }                                                                                                         \
+  }
+#define GSAJ_TRACE_END(NAME)                                                                                  \
+  {                                                                                                           \
+    const unsigned tw_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);                                 \
+    if ((threadIdx.x & 63) == 0 && tw_ < GSAJ_TRACE_MAX) g_trace_##NAME[4 * tw_ + 1] = wall_clock64();        \
+  }
+#else
+#define GSAJ_TRACE_DEFINE(NAME)
+#define GSAJ_TRACE_BEGIN(NAME)
+#define GSAJ_TRACE_END(NAME)
+#endif

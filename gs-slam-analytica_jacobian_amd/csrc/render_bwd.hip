@@ -35,6 +35,8 @@
 #define SLOTS 8        // accepted entries per phase-2 batch
 #define WU_STRIDE 65   // float2 per slot row (64 pixels + 1: conflict-free ds_read_b64 in phase 2)
 
+GSAJ_TRACE_DEFINE(bwd)
+
 __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int gx, const uint2 *__restrict__ ranges,
                                                     const float4 *__restrict__ records, const float *__restrict__ bg,
                                                     const float *__restrict__ final_T,
@@ -49,6 +51,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int gx, const 
   __shared__ float4 seed_all[4 * 64];                  // [wave][pixel] (dL/dC rgb, dL/dD)
   __shared__ uint32_t wave_max[4];
   if (counters[4]) return;  // aborted async frame
+  GSAJ_TRACE_BEGIN(bwd)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   float2 *wu = wu_all + wave * SLOTS * WU_STRIDE;
   float4 *seed = seed_all + wave * 64;
@@ -252,6 +255,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int gx, const 
     __syncthreads();
     hi = lo;
   }
+  GSAJ_TRACE_END(bwd)
 }
 
 int launch_render_backward(int R, int W, int H, int grid_x, int grid_y, const float *bg, const BinWS &b,

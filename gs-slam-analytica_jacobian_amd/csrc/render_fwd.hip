@@ -17,6 +17,8 @@
 
 #define FWD_CHUNK 64  // records staged per wave per trip
 
+GSAJ_TRACE_DEFINE(fwd)
+
 __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int gx, const uint2 *__restrict__ ranges,
                                                     const float4 *__restrict__ records, const float *__restrict__ bg,
                                                     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
@@ -28,6 +30,7 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int gx, const 
   // tile read the same records; the repeats are served by L1/L2.
   __shared__ float4 rec_all[4 * FWD_CHUNK * REC_F4];
   if (counters[4]) return;  // aborted async frame
+  GSAJ_TRACE_BEGIN(fwd)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   float4 *rec = rec_all + wave * FWD_CHUNK * REC_F4;
   const int tile = blockIdx.x;
@@ -124,6 +127,7 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int gx, const 
     out_depth[pid] = Dp;
     out_opacity[pid] = 1.f - T;
   }
+  GSAJ_TRACE_END(fwd)
 }
 
 int launch_render_forward(int W, int H, int grid_x, int grid_y, const float *bg, const BinWS &b, const ImageWS &im,

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Per-wave schedule trace of k_render_fwd / k_render_bwd on the benchmark workload.
+
+Needs a library built with the trace hooks:   make -C gs-slam-analytica_jacobian_amd/csrc clean all EXTRA=-DGSAJ_BLOCK_TRACE
+Writes gpurun_out/block_trace_{fwd,bwd}.npy  ([waves, 4] uint64: start, end (10 ns ticks), HW_ID, XCC_ID) and prints a summary.
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "gs-slam-analytica_jacobian_amd"))
+import torch  # noqa: E402
+from gsaj import _lib, synthetic as syn  # noqa: E402
+from gsaj.rasterizer import FrameContext  # noqa: E402
+
+
+def main():
+    wl = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    cam, sc = syn.config_scene(wl)
+    P, W, H, M = sc["means3D"].shape[0], cam["W"], cam["H"], sc["shs"].shape[1]
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)  # noqa: E731
+    ctx = FrameContext(P, W, H, M, dev)
+    fa = dict(bg=torch.zeros(3, device=dev), means3D=t(sc["means3D"]), opacities=t(sc["opacities"]), viewmatrix=t(cam["viewmatrix"]),
+              projmatrix=t(cam["projmatrix"]), campos=t(cam["campos"]), tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], sh_degree=3,
+              shs=t(sc["shs"]), scales=t(sc["scales"]), rotations=t(sc["rotations"]))
+    rng = np.random.default_rng(0)
+    dLc, dLd = t(rng.normal(size=(3, H, W)) / (3 * H * W)), t(rng.normal(size=(1, H, W)) / (H * W))
+    for _ in range(3):
+        ctx.forward(**fa)
+        ctx.backward(bg=fa["bg"], means3D=fa["means3D"], viewmatrix=fa["viewmatrix"], projmatrix=fa["projmatrix"],
+                     projmatrix_raw=t(cam["projmatrix_raw"]), campos=fa["campos"], tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"],
+                     dL_dcolor=dLc, dL_ddepth=dLd, sh_degree=3, shs=fa["shs"], scales=fa["scales"], rotations=fa["rotations"])
+    torch.cuda.synchronize()
+    nw = ((W + 15) // 16) * ((H + 15) // 16) * 4
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    for name in ("fwd", "bwd"):
+        fn = getattr(lib, "gsaj_trace_read_" + name)
+        fn.argtypes, fn.restype = [ctypes.c_void_p, ctypes.c_int], ctypes.c_int
+        buf = np.zeros((nw, 4), np.uint64)
+        assert fn(buf.ctypes.data, nw) == 0
+        np.save(os.path.join(ROOT, "gpurun_out", "block_trace_%s.npy" % name), buf)
+        s, e = buf[:, 0].astype(np.int64), buf[:, 1].astype(np.int64)
+        t0 = s.min()
+        life = (e - s) * 0.01
+        print(name, "waves", nw, "span us %.1f" % ((e.max() - t0) * 0.01), "mean life us %.1f" % life.mean(),
+              "p5/p50/p95 life %.1f %.1f %.1f" % tuple(np.percentile(life, [5, 50, 95])),
+              "start p50/p95/max us %.1f %.1f %.1f" % tuple(np.percentile((s - t0) * 0.01, [50, 95, 100])),
+              "end p5/p50/p95 us %.1f %.1f %.1f" % tuple(np.percentile((e - t0) * 0.01, [5, 50, 95])))
+
+
+if __name__ == "__main__":
+    main()

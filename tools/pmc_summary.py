@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Average rocprofv3 --pmc counter values per kernel name.
+
+usage: pmc_summary.py OUT.json DIR [DIR ...]   (each DIR holds *_counter_collection.csv of one --pmc pass)
+"""
+import csv
+import glob
+import json
+import sys
+from collections import defaultdict
+
+
+def main():
+    out, dirs = sys.argv[1], sys.argv[2:]
+    acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    for d in dirs:
+        for path in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
+            with open(path) as f:
+                for row in csv.DictReader(f):
+                    name = row["Kernel_Name"].split("(")[0]
+                    a = acc[name][row["Counter_Name"]]
+                    a[0] += float(row["Counter_Value"])
+                    a[1] += 1
+    res = {k: {c: v[0] / v[1] for c, v in sorted(cs.items())} for k, cs in sorted(acc.items()) if k.startswith(("k_", "void k_"))}
+    with open(out, "w") as f:
+        json.dump(res, f, indent=1)
+    for k, cs in res.items():
+        print(k, {c: round(v, 1) for c, v in cs.items()})
+
+
+if __name__ == "__main__":
+    main()
