@@ -34,10 +34,12 @@
 #define BWD_ROUND 64   // list entries staged per workgroup round
 #define SLOTS 8        // accepted entries per phase-2 batch
 #define WU_STRIDE 65   // float2 per slot row (64 pixels + 1: conflict-free ds_read_b64 in phase 2)
+#define ACC_C 10       // partials per (entry, wave)
+#define ACC_STRIDE (BWD_ROUND + 1)  // acc[wave][partial][entry]: the end-of-round merge reads consecutive words
 
 GSAJ_TRACE_DEFINE(bwd)
 
-__global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int gx, const uint2 *__restrict__ ranges,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_render_bwd(int W, int H, int gx, const uint2 *__restrict__ ranges,
                                                     const float4 *__restrict__ records, const float *__restrict__ bg,
                                                     const float *__restrict__ final_T,
                                                     const uint32_t *__restrict__ n_contrib,
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int gx, const 
                                                     float4 *__restrict__ inst_grad,
                                                     const uint32_t *__restrict__ counters) {
   __shared__ float4 rec[BWD_ROUND * REC_F4];
-  __shared__ float acc[BWD_ROUND * 4 * IGRAD_F];      // [entry][wave][12]
+  __shared__ __attribute__((aligned(16))) float acc[4 * ACC_C * ACC_STRIDE];  // [wave][partial][entry]
   __shared__ float2 wu_all[4 * SLOTS * WU_STRIDE];     // [wave][slot][pixel] (w, u)
   __shared__ float4 seed_all[4 * 64];                  // [wave][pixel] (dL/dC rgb, dL/dD)
   __shared__ uint32_t wave_max[4];
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int gx, const 
     }
     {
       float4 *z = reinterpret_cast<float4 *>(acc);
-      for (int i = tid; i < n * 4 * (IGRAD_F / 4); i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = tid; i < 4 * ACC_C * ACC_STRIDE / 4; i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
 
@@ -179,10 +181,10 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int gx, const 
         if (live && (lane & 8) == 0) {
           const int r = lane >> 4;
           const int k = ((r & 1) << 1) | (r >> 1);
-          float *a = acc + (j * 4 + wave) * IGRAD_F;
-          a[k] = x0;
-          a[4 + k] = x1;
-          if ((r & 1) == 0) a[8 + (r >> 1)] = x2;
+          float *a = acc + wave * ACC_C * ACC_STRIDE + j;
+          a[k * ACC_STRIDE] = x0;
+          a[(4 + k) * ACC_STRIDE] = x1;
+          if ((r & 1) == 0) a[(8 + (r >> 1)) * ACC_STRIDE] = x2;
         }
         nslot = 0;
       };
@@ -237,16 +239,14 @@ __global__ __launch_bounds__(256) void k_render_bwd(int W, int H, int gx, const 
     }
     __syncthreads();
     if (tid < n) {
-      const float4 *a = reinterpret_cast<const float4 *>(acc) + tid * 4 * (IGRAD_F / 4);
-      float4 s0 = a[0], s1 = a[1], s2 = a[2];
+      float t[ACC_C];
 #pragma unroll
-      for (int w = 1; w < 4; w++) {
-        const float4 b0 = a[w * 3 + 0], b1 = a[w * 3 + 1], b2 = a[w * 3 + 2];
-        s0.x += b0.x; s0.y += b0.y; s0.z += b0.z; s0.w += b0.w;
-        s1.x += b1.x; s1.y += b1.y; s1.z += b1.z; s1.w += b1.w;
-        s2.x += b2.x; s2.y += b2.y;
+      for (int c = 0; c < ACC_C; c++) {
+        const float *a = acc + c * ACC_STRIDE + tid;
+        t[c] = ((a[0] + a[ACC_C * ACC_STRIDE]) + a[2 * ACC_C * ACC_STRIDE]) + a[3 * ACC_C * ACC_STRIDE];  // fixed order
       }
-      s2.z = 0.f; s2.w = 0.f;
+      const float4 s0 = make_float4(t[0], t[1], t[2], t[3]), s1 = make_float4(t[4], t[5], t[6], t[7]),
+                   s2 = make_float4(t[8], t[9], 0.f, 0.f);
       float4 *dst = inst_grad + (size_t)__float_as_uint(rec[tid * REC_F4 + 2].w) * REC_F4;  // emission slot
       dst[0] = s0;
       dst[1] = s1;

@@ -16,10 +16,11 @@
 #include "wave_reduce.h"
 
 #define FWD_CHUNK 64  // records staged per wave per trip
+#define FWD_PAD 8     // inert records after the packed ones: the pipelined entry loop reads up to 7 slots past the last
 
 GSAJ_TRACE_DEFINE(fwd)
 
-__global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int gx, const uint2 *__restrict__ ranges,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_render_fwd(int W, int H, int gx, const uint2 *__restrict__ ranges,
                                                     const float4 *__restrict__ records, const float *__restrict__ bg,
                                                     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                                                     float *__restrict__ out_color, float *__restrict__ out_depth,
@@ -28,11 +29,11 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int gx, const 
   // Each wave (one 8x8 quadrant) walks the tile list on its own: private 64-record staging area, no
   // workgroup barrier anywhere, so a quadrant never waits for a slower neighbour.  The four waves of a
   // tile read the same records; the repeats are served by L1/L2.
-  __shared__ float4 rec_all[4 * FWD_CHUNK * REC_F4];
+  __shared__ float4 rec_all[4 * (FWD_CHUNK + FWD_PAD) * REC_F4];
   if (counters[4]) return;  // aborted async frame
   GSAJ_TRACE_BEGIN(fwd)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  float4 *rec = rec_all + wave * FWD_CHUNK * REC_F4;
+  float4 *rec = rec_all + wave * (FWD_CHUNK + FWD_PAD) * REC_F4;
   const int tile = blockIdx.x;
   const int ty = tile / gx, tx = tile - ty * gx;
   const int px = tx * TILE + (wave & 1) * 8 + (lane & 7);
@@ -45,73 +46,104 @@ __global__ __launch_bounds__(256) void k_render_fwd(int W, int H, int gx, const 
   bool done = !inside;
   float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f, Dp = 0.f;
   uint32_t last = 0;
+  bool counting = true;  // wave-uniform: some pixel of the quadrant still has T > 0.5 (only those can "touch")
 
-  if (__builtin_amdgcn_ballot_w64(!done) != 0ull) {
+  // One packed list entry for this lane's pixel.  g = (mean x, mean y, depth), k = conic pre-scaled so that
+  // k.x dx^2 + k.y dx dy + k.z dy^2 = log2(e) * power, k.w = opacity, c = (rgb, 1-based list position).
+  // A pixel that skips the entry runs the same arithmetic with alpha = 0: T, C, D come out unchanged.
+  auto composite = [&](const float4 g, const float4 k, const float4 c, float &test_T) -> bool {
+    const float dx = g.x - pxf, dy = g.y - pyf;
+    const float p2 = dx * (k.x * dx + k.y * dy) + (k.z * dy) * dy;
+    const float alpha0 = fminf(0.99f, k.w * __builtin_amdgcn_exp2f(p2));
+    bool ok = !done && p2 <= 0.0f && alpha0 >= (1.0f / 255.0f);
+    test_T = T - alpha0 * T;
+    const bool sat = ok && test_T < 0.0001f;  // this pixel is saturated: stop before this entry
+    done = done || sat;
+    ok = ok && !sat;
+    const float w = ok ? alpha0 * T : 0.f;
+    Cr += c.x * w;
+    Cg += c.y * w;
+    Cb += c.z * w;
+    Dp += g.z * w;
+    T = ok ? test_T : T;
+    last = ok ? __float_as_uint(c.w) : last;
+    return ok;
+  };
+
+  if (__builtin_amdgcn_ballot_w64(!done) != 0ull && range.x < range.y) {
+    // the next chunk's records are requested from HBM/L2 before the current chunk is composited
+    float4 q0, q1, q2;
+    auto fetch = [&](uint32_t base) {
+      if (base + (uint32_t)lane < range.y) {
+        const float4 *src = records + (size_t)(base + lane) * REC_F4;
+        q0 = src[0], q1 = src[1], q2 = src[2];
+      }
+    };
+    fetch(range.x);
     for (uint32_t base = range.x; base < range.y; base += FWD_CHUNK) {
       const int m = min((uint32_t)FWD_CHUNK, range.y - base);
-      // stage: lane l fetches record base+l (coalesced 3 KB), tests it against the quadrant, publishes it
+      // stage: lane l holds record base+l and tests it against the quadrant; the records the quadrant can see
+      // are packed to the front of the wave's LDS area in list order
       bool rel = false;
-      if (lane < m) {
-        const float4 *src = records + (size_t)(base + lane) * REC_F4;
-        const float4 q0 = src[0], q1 = src[1], q2 = src[2];
-        rec[lane * REC_F4 + 0] = q0;
-        rec[lane * REC_F4 + 1] = q1;
-        rec[lane * REC_F4 + 2] = q2;
-        rel = quadrant_relevant(q0.x, q0.y, q1.x, q1.y, q1.z, q1.w, qx0, qy0);
+      if (lane < m) rel = quadrant_relevant(q0.x, q0.y, q1.x, q1.y, q1.z, q1.w, qx0, qy0);
+      const unsigned long long todo = __builtin_amdgcn_ballot_w64(rel);
+      const int nrel = __popcll(todo);
+      __builtin_amdgcn_wave_barrier();
+      if (rel) {
+        const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(todo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)todo, 0u));
+        const float L2E = 1.4426950408889634f;
+        rec[slot * REC_F4 + 0] = q0;
+        rec[slot * REC_F4 + 1] = make_float4((-0.5f * L2E) * q1.x, -L2E * q1.y, (-0.5f * L2E) * q1.z, q1.w);
+        rec[slot * REC_F4 + 2] = make_float4(q2.x, q2.y, q2.z, __uint_as_float(base - range.x + (uint32_t)lane + 1u));
       }
-      unsigned long long todo = __builtin_amdgcn_ballot_w64(rel);
-      int cnt = 0;  // lane l: #pixels of this wave that count entry base+l as "touched"
+      if (lane < FWD_PAD * REC_F4) rec[nrel * REC_F4 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);  // inert sentinels (opacity 0)
+      fetch(base + FWD_CHUNK);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      int cnt = 0;  // lane l: #pixels of this wave that count packed entry l as "touched"
       bool wave_done = false;
-      if (todo != 0ull) {
-        // software pipeline: the geometry of the NEXT relevant record is requested from LDS before the
-        // current one is evaluated (its colour row is fetched only if some lane accepts the entry)
-        int jn = __builtin_ctzll(todo);
-        todo &= todo - 1ull;
-        float4 n0 = rec[jn * REC_F4 + 0], n1 = rec[jn * REC_F4 + 1];
-        while (true) {
-          const int jj = jn;
-          const float4 r0 = n0, r1 = n1;
-          const bool more = todo != 0ull;
-          if (more) {
-            jn = __builtin_ctzll(todo);
-            todo &= todo - 1ull;
-            n0 = rec[jn * REC_F4 + 0];
-            n1 = rec[jn * REC_F4 + 1];
+      // two entries per step; the records of the next step are requested from LDS before this step's arithmetic
+      float4 a0 = rec[0], a1 = rec[1], a2 = rec[2], b0 = rec[3], b1 = rec[4], b2 = rec[5];
+      for (int i = 0; i < nrel; i += 4) {
+        const float4 c0 = rec[i * REC_F4 + 6], c1 = rec[i * REC_F4 + 7], c2 = rec[i * REC_F4 + 8];
+        const float4 d0 = rec[i * REC_F4 + 9], d1 = rec[i * REC_F4 + 10], d2 = rec[i * REC_F4 + 11];
+        {
+          float tA, tB;
+          const bool okA = composite(a0, a1, a2, tA);
+          const bool okB = composite(b0, b1, b2, tB);
+          if (counting) {
+            const int nA = __popcll(__builtin_amdgcn_ballot_w64(okA && tA > 0.5f));
+            const int nB = __popcll(__builtin_amdgcn_ballot_w64(okB && tB > 0.5f));
+            cnt = (lane == i) ? nA : cnt;
+            cnt = (lane == i + 1) ? nB : cnt;
+            counting = __builtin_amdgcn_ballot_w64(T > 0.5f) != 0ull;
           }
-          const float dx = r0.x - pxf, dy = r0.y - pyf;
-          const float power = -0.5f * (r1.x * dx * dx + r1.z * dy * dy) - r1.y * dx * dy;
-          const float alpha = fminf(0.99f, r1.w * __expf(power));
-          const float test_T = T * (1.f - alpha);
-          bool ok = !done && power <= 0.0f && alpha >= (1.0f / 255.0f);
-          if (ok && test_T < 0.0001f) {  // this pixel is saturated: stop before this entry
-            done = true;
-            ok = false;
+        }
+        a0 = rec[i * REC_F4 + 12], a1 = rec[i * REC_F4 + 13], a2 = rec[i * REC_F4 + 14];
+        b0 = rec[i * REC_F4 + 15], b1 = rec[i * REC_F4 + 16], b2 = rec[i * REC_F4 + 17];
+        {
+          float tC, tD;
+          const bool okC = composite(c0, c1, c2, tC);
+          const bool okD = composite(d0, d1, d2, tD);
+          if (counting) {
+            const int nC = __popcll(__builtin_amdgcn_ballot_w64(okC && tC > 0.5f));
+            const int nD = __popcll(__builtin_amdgcn_ballot_w64(okD && tD > 0.5f));
+            cnt = (lane == i + 2) ? nC : cnt;
+            cnt = (lane == i + 3) ? nD : cnt;
+            counting = __builtin_amdgcn_ballot_w64(T > 0.5f) != 0ull;
           }
-          if (__builtin_amdgcn_ballot_w64(ok) != 0ull) {
-            const float4 r2 = rec[jj * REC_F4 + 2];
-            if (ok) {
-              const float w = alpha * T;
-              Cr += r2.x * w;
-              Cg += r2.y * w;
-              Cb += r2.z * w;
-              Dp += r0.z * w;
-              T = test_T;
-              last = base - range.x + (uint32_t)jj + 1u;
-            }
-            const int touched = __popcll(__builtin_amdgcn_ballot_w64(ok && test_T > 0.5f));
-            cnt = (lane == jj) ? touched : cnt;  // each entry is visited once per chunk
-          }
-          if (__builtin_amdgcn_ballot_w64(!done) == 0ull) {
-            wave_done = true;
-            break;
-          }
-          if (!more) break;
+        }
+        if (__builtin_amdgcn_ballot_w64(!done) == 0ull) {
+          wave_done = true;
+          break;
         }
       }
-      if (lane < m && cnt > 0) {
+      if (lane < nrel && cnt > 0) {
         const uint32_t id = __float_as_uint(rec[lane * REC_F4 + 0].w);
         atomicAdd(&n_touched[id], cnt);
       }
+      __builtin_amdgcn_wave_barrier();
       if (wave_done) break;  // whole quadrant saturated
     }
   }
