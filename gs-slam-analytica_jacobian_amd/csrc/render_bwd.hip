@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     gD = dL_dpix_depth[pid];
   }
   seed[lane] = make_float4(gC0, gC1, gC2, gD);
-  const float bg_dot = bg[0] * gC0 + bg[1] * gC1 + bg[2] * gC2;
+  const float Tf_bg = T_final * (bg[0] * gC0 + bg[1] * gC1 + bg[2] * gC2);
   const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
 
   // furthest last-contributor of this quadrant and of the tile
@@ -134,43 +134,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
       // ---- phase 2: moments of the queued (w, u) rows -> per-entry totals in this wave's acc slots ----
       auto flush = [&]() {
+        // Lane (slot s, pixel row y): the row's 8 pixels sit at x' = -3.5 .. 3.5 around the quadrant centre column, so
+        // three running sums of w (1, x', x'^2) give every second moment of the row about the Gaussian's mean:
+        // dx = ax - x' (ax = mean x - centre column), dy constant along the row.  Slots beyond nslot hold stale rows;
+        // slots never mix, and only live ones are stored.
         const int j = __shfl(slot_entry, p2_slot);
-        const bool live = p2_slot < nslot;
-        const float4 e0 = rec[(live ? j : 0) * REC_F4 + 0];
-        const float4 e1 = rec[(live ? j : 0) * REC_F4 + 1];
-        const float dy = e0.y - p2_py;
-        float m0 = 0.f, mx = 0.f, my = 0.f, mxx = 0.f, mxy = 0.f, myy = 0.f, u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f;
+        const float4 e0 = rec[j * REC_F4 + 0];
+        const float4 e1 = rec[j * REC_F4 + 1];
+        const float ax = e0.x - (qx0 + 3.5f), dy = e0.y - p2_py;
+        float m0 = 0.f, m1 = 0.f, m2 = 0.f, u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f;
 #pragma unroll
         for (int it = 0; it < 8; it++) {
           const int pix = p2_row * 8 + it;
           const float2 q = wu[p2_slot * WU_STRIDE + pix];
           const float4 sd = seed[pix];
-          const float dx = e0.x - (qx0 + (float)it);
-          const float wdx = q.x * dx, wdy = q.x * dy;
+          const float xc = (float)it - 3.5f;
           m0 += q.x;
-          mx += wdx;
-          my += wdy;
-          mxx += wdx * dx;
-          mxy += wdx * dy;
-          myy += wdy * dy;
+          m1 += q.x * xc;
+          m2 += q.x * (xc * xc);
           u0 += q.y * sd.x;
           u1 += q.y * sd.y;
           u2 += q.y * sd.z;
           u3 += q.y * sd.w;
         }
+        const float swdx = ax * m0 - m1;               // sum w dx
+        const float swdy = dy * m0;                    // sum w dy
+        const float swdx2 = ax * (swdx - m1) + m2;     // sum w dx^2 = ax (ax m0 - 2 m1) + m2
         // the 10 partials are linear in the moments: convert per pixel row, then combine the 8 rows
         float v[10];
-        v[0] = -(e1.x * mx + e1.y * my) * ddelx_dx;  // dL/dmean2D.x  (dG/ddx = -G (a dx + b dy))
-        v[1] = -(e1.z * my + e1.y * mx) * ddely_dy;  // dL/dmean2D.y
-        v[2] = -0.5f * mxx;                          // dL/dconic a
-        v[3] = -0.5f * mxy;                          // dL/dconic b
-        v[4] = -0.5f * myy;                          // dL/dconic c
-        v[5] = m0 * __builtin_amdgcn_rcpf(e1.w);     // dL/dopacity = sum G dL/dalpha = sum w / o
-        v[6] = u0; v[7] = u1; v[8] = u2; v[9] = u3;  // dL/dcolour, dL/ddepth
-        if (!live) {
-#pragma unroll
-          for (int c = 0; c < 10; c++) v[c] = 0.f;
-        }
+        v[0] = -(e1.x * swdx + e1.y * swdy) * ddelx_dx;  // dL/dmean2D.x  (dG/ddx = -G (a dx + b dy))
+        v[1] = -(e1.z * swdy + e1.y * swdx) * ddely_dy;  // dL/dmean2D.y
+        v[2] = -0.5f * swdx2;                            // dL/dconic a
+        v[3] = -0.5f * (dy * swdx);                      // dL/dconic b
+        v[4] = -0.5f * (dy * swdy);                      // dL/dconic c
+        v[5] = m0 * __builtin_amdgcn_rcpf(e1.w);         // dL/dopacity = sum G dL/dalpha = sum w / o
+        v[6] = u0; v[7] = u1; v[8] = u2; v[9] = u3;      // dL/dcolour, dL/ddepth
         const float w0 = merge32(v[0], v[1]), w1 = merge32(v[2], v[3]), w2 = merge32(v[4], v[5]), w3 = merge32(v[6], v[7]),
                     w4 = merge32(v[8], v[9]);
         float x0 = merge16(w0, w1), x1 = merge16(w2, w3), x2 = merge16(w4, w4);
@@ -178,7 +176,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         x1 = dpp_add<0x128>(x1);
         x2 = dpp_add<0x128>(x2);
         // 16-lane row r = lane>>4 now holds, for slot lane&7: x0 -> v[{0,2,1,3}[r]], x1 -> v[{4,6,5,7}[r]], x2 -> v[{8,8,9,9}[r]]
-        if (live && (lane & 8) == 0) {
+        if (p2_slot < nslot && (lane & 8) == 0) {
           const int r = lane >> 4;
           const int k = ((r & 1) << 1) | (r >> 1);
           float *a = acc + wave * ACC_C * ACC_STRIDE + j;
@@ -218,15 +216,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const float G = valid ? G0 : 0.f;
             const float inv1ma = __builtin_amdgcn_rcpf(1.f - alpha);
             T = T * inv1ma;  // T <- T / (1 - alpha)
-            float dL_dalpha = (r2.x - accC0) * gC0 + (r2.y - accC1) * gC1 + (r2.z - accC2) * gC2 + (r0.z - accD) * gD;
-            dL_dalpha = dL_dalpha * T - (T_final * inv1ma) * bg_dot;
-            // accum_rec for the next (nearer) entry: alpha c + (1 - alpha) accum_rec (backward.cu:799,811,
-            // applied here instead of lazily at the top of the next iteration -- same arithmetic)
-            const float oma = 1.f - alpha;
-            accC0 = alpha * r2.x + oma * accC0;
-            accC1 = alpha * r2.y + oma * accC1;
-            accC2 = alpha * r2.z + oma * accC2;
-            accD = alpha * r0.z + oma * accD;
+            const float d0 = r2.x - accC0, d1 = r2.y - accC1, d2 = r2.z - accC2, d3 = r0.z - accD;
+            float dL_dalpha = d0 * gC0 + d1 * gC1 + d2 * gC2 + d3 * gD;
+            dL_dalpha = dL_dalpha * T - Tf_bg * inv1ma;
+            // accum_rec for the next (nearer) entry: alpha c + (1 - alpha) accum_rec (backward.cu:799,811), written
+            // as accum_rec + alpha (c - accum_rec); applied here instead of lazily at the top of the next iteration
+            accC0 += alpha * d0;
+            accC1 += alpha * d1;
+            accC2 += alpha * d2;
+            accD += alpha * d3;
             wu[nslot * WU_STRIDE + lane] = make_float2((r1.w * dL_dalpha) * G, alpha * T);
             slot_entry = (lane == nslot) ? j : slot_entry;
             nslot++;
