@@ -31,7 +31,7 @@
 #include "gsaj_common.h"
 #include "wave_reduce.h"
 
-#define BWD_ROUND 64   // list entries staged per workgroup round
+#define BWD_ROUND 56   // list entries staged per workgroup round (LDS <= 32 KB: five workgroups per CU)
 #define SLOTS 8        // accepted entries per phase-2 batch
 #define WU_STRIDE 65   // float2 per slot row (64 pixels + 1: conflict-free ds_read_b64 in phase 2)
 #define ACC_C 10       // partials per (entry, wave)
@@ -39,7 +39,7 @@
 
 GSAJ_TRACE_DEFINE(bwd)
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_render_bwd(int W, int H, int gx, const uint2 *__restrict__ ranges,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_render_bwd(int W, int H, int gx, const uint2 *__restrict__ ranges,
                                                     const float4 *__restrict__ records, const float *__restrict__ bg,
                                                     const float *__restrict__ final_T,
                                                     const uint32_t *__restrict__ n_contrib,

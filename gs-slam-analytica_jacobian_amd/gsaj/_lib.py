@@ -11,7 +11,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(PKG_ROOT, "csrc")
-LIB_PATH = os.path.join(PKG_ROOT, "lib", "libgsaj_hip.so")
+LIB_PATH = os.environ.get("GSAJ_LIB_PATH") or os.path.join(PKG_ROOT, "lib", "libgsaj_hip.so")  # override: A/B kernel experiments
 HEADER = os.path.join(os.path.dirname(PKG_ROOT), "include", "gsaj.h")
 
 c_int, c_float, c_double, c_size_t, c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_size_t, ctypes.c_void_p
