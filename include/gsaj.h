@@ -170,6 +170,24 @@ int gsaj_debug_export(int P, int R, int W, int H, const void *geom_ws, const voi
 int gsaj_profile_begin(int max_records);
 int gsaj_profile_end(float *stage_ms /*host [GSAJ_NUM_STAGES]*/, int *stage_launches /*host [GSAJ_NUM_STAGES]*/);
 
+/* ---- losses + pixel-gradient seeds ---------------------------------------------
+ * Replaces the ~15 full-frame torch kernels + autograd of get_loss_tracking / get_loss_mapping
+ * (reference utils/slam_utils.py:56-128) by one pass: reads color [3,H,W], depth [1,H,W], opacity [1,H,W], the
+ * ground truth gt_color [3,H,W], gt_depth [H,W] (RGB-D only) and the optional tracking grad_mask [H,W] (bytes,
+ * non-zero = keep; slam_utils.py:69), the exposure scalars a, b on the device (ignored with NO_EXPOSURE, i.e.
+ * get_loss_mapping(initialization=True)), and writes dL/dcolor [3,H,W], dL/ddepth [1,H,W] -- the two inputs of
+ * gsaj_rasterize_backward -- optionally dL/dopacity [1,H,W] (the reference's rasteriser ignores it), and
+ * out_scalars[5] = {loss, L_rgb, L_depth, dL/da, dL/db} on the device.  Deterministic (no float atomics).
+ * loss_ws: gsaj_loss_workspace_bytes(W, H) bytes, ZEROED ONCE by the caller when allocated. */
+#define GSAJ_LOSS_TRACKING 1    /* opacity weight, grad_mask, opacity > 0.95 depth gate (get_loss_tracking*) */
+#define GSAJ_LOSS_MONOCULAR 2   /* config["Training"]["monocular"]: colour term only */
+#define GSAJ_LOSS_NO_EXPOSURE 4 /* image_ab = image (get_loss_mapping(initialization=True)) */
+size_t gsaj_loss_workspace_bytes(int W, int H);
+int gsaj_loss_seeds(int W, int H, int flags, float alpha, float rgb_boundary_threshold, const float *color,
+                    const float *depth, const float *opacity, const float *gt_color, const float *gt_depth,
+                    const uint8_t *grad_mask, const float *exposure_a, const float *exposure_b, float *dL_dcolor,
+                    float *dL_ddepth, float *dL_dopacity, float *out_scalars, void *loss_ws, void *stream);
+
 /* ---- dense analytic path (NumPy-path semantics) ------------------ */
 size_t gsaj_dense_workspace_bytes(int N, int W, int H);
 /* N depth-sorted Gaussians: means2D [N,2] (pixels), covs2D [N,2,2], colors [N,3], depths [N], opac [N];

@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""One tracking iteration (render -> loss -> backward to dL/dtau) on cfg2, three ways:
+  A. drop-in: gaussian_renderer.render() autograd function + torch losses (utils/slam_utils.get_loss_tracking) + .backward()
+  B. FrameContext (no host sync) + torch loss / autograd for the seeds
+  C. FrameContext + gsaj_loss_seeds (one kernel for loss + seeds)
+Prints ms per iteration (synchronised wall clock over N iterations)."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "gs-slam-analytica_jacobian_amd"))
+import torch  # noqa: E402
+from gsaj import losses, synthetic as syn  # noqa: E402
+from gsaj.rasterizer import FrameContext  # noqa: E402
+from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer  # noqa: E402
+from utils import slam_utils  # noqa: E402
+
+
+class View:
+    pass
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+    dev = torch.device("cuda:0")
+    cam, sc = syn.config_scene("cfg2")
+    P, W, H, M = sc["means3D"].shape[0], cam["W"], cam["H"], sc["shs"].shape[1]
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)  # noqa: E731
+    means, opac, shs, scales, rots = t(sc["means3D"]), t(sc["opacities"]), t(sc["shs"]), t(sc["scales"]), t(sc["rotations"])
+    view, proj, proj_raw, campos = t(cam["viewmatrix"]), t(cam["projmatrix"]), t(cam["projmatrix_raw"]), t(cam["campos"])
+    bg = torch.zeros(3, device=dev)
+    rng = np.random.default_rng(0)
+    v = View()
+    v.original_image = t(rng.uniform(0, 1, (3, H, W)))
+    v.depth = rng.uniform(0.5, 4, (H, W)).astype(np.float32)
+    v.grad_mask = torch.as_tensor(rng.uniform(size=(1, H, W)) < 0.7, device=dev)
+    v.exposure_a = torch.zeros(1, device=dev, requires_grad=True)
+    v.exposure_b = torch.zeros(1, device=dev, requires_grad=True)
+    cfg = {"Training": {"monocular": False, "rgb_boundary_threshold": 0.01, "alpha": 0.95}}
+    gt_depth_dev = t(v.depth)
+
+    def timed(fn):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / n
+
+    # A: drop-in autograd path
+    theta = torch.zeros(3, device=dev, requires_grad=True)
+    rho = torch.zeros(3, device=dev, requires_grad=True)
+    means2D = torch.zeros((P, 3), device=dev, requires_grad=True)
+    st = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=bg,
+                                       scale_modifier=1.0, viewmatrix=view, projmatrix=proj, projmatrix_raw=proj_raw, sh_degree=3,
+                                       campos=campos, prefiltered=False, debug=False)
+    rast = GaussianRasterizer(st)
+
+    def iter_a():
+        color, radii, depth, opacity, n_touched = rast(means3D=means, means2D=means2D, opacities=opac, shs=shs, scales=scales,
+                                                       rotations=rots, theta=theta, rho=rho)
+        loss = slam_utils.get_loss_tracking(cfg, color, depth, opacity, v)
+        loss.backward()
+        theta.grad = None
+        rho.grad = None
+        means2D.grad = None
+
+    ctx = FrameContext(P, W, H, M, dev)
+    fa = dict(bg=bg, means3D=means, opacities=opac, viewmatrix=view, projmatrix=proj, campos=campos, tanfovx=cam["tanfovx"],
+              tanfovy=cam["tanfovy"], sh_degree=3, shs=shs, scales=scales, rotations=rots)
+    ctx.forward(**fa)
+
+    def bwd(dc, dd):
+        ctx.backward(bg=bg, means3D=means, viewmatrix=view, projmatrix=proj, projmatrix_raw=proj_raw, campos=campos,
+                     tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], dL_dcolor=dc, dL_ddepth=dd, sh_degree=3, shs=shs, scales=scales,
+                     rotations=rots)
+
+    def iter_b():
+        color, depth, opacity = _fwd_b()
+        c = color.detach().requires_grad_(True)
+        d = depth.detach().requires_grad_(True)
+        loss = slam_utils.get_loss_tracking(cfg, c, d, opacity.detach(), v)
+        loss.backward()
+        bwd(c.grad.contiguous(), d.grad.contiguous())
+
+    def _fwd_b():
+        ctx.forward(sync=False, **fa)
+        return ctx.color, ctx.depth, ctx.opacity
+
+    ls = losses.LossSeeds(W, H, dev)
+
+    def iter_c():
+        ctx.forward(sync=False, **fa)
+        o = ls(losses.TRACKING, 0.95, 0.01, ctx.color, ctx.depth, ctx.opacity, v.original_image, gt_depth_dev,
+               v.grad_mask, v.exposure_a.detach(), v.exposure_b.detach())
+        bwd(o["dL_dcolor"], o["dL_ddepth"])
+
+    ms_a, ms_b, ms_c = timed(iter_a), timed(iter_b), timed(iter_c)
+    print("tracking iteration, cfg2 (%d Gaussians, %dx%d): A drop-in autograd %.3f ms | B FrameContext + torch loss %.3f ms | "
+          "C FrameContext + gsaj_loss_seeds %.3f ms" % (P, W, H, ms_a, ms_b, ms_c))
+
+
+if __name__ == "__main__":
+    main()
