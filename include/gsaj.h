@@ -188,6 +188,24 @@ int gsaj_loss_seeds(int W, int H, int flags, float alpha, float rgb_boundary_thr
                     const uint8_t *grad_mask, const float *exposure_a, const float *exposure_b, float *dL_dcolor,
                     float *dL_ddepth, float *dL_dopacity, float *out_scalars, void *loss_ws, void *stream);
 
+/* ---- tracking pose step on the device -------------------------------------------
+ * One launch = torch.optim.Adam.step() on (cam_trans_delta, cam_rot_delta, exposure_a, exposure_b) as set up in
+ * slam_frontend.py:135-160 + update_pose (reference utils/pose_utils.py:76-93) + the camera matrices of
+ * camera_utils.py:95-109, with no host read-back.  dL_dtau = [rho(3), theta(3)] is the dL_dtau_sum of
+ * gsaj_rasterize_backward; dL_dexposure = {dL/da, dL/db} (out_scalars + 3 of gsaj_loss_seeds) or NULL.
+ * projection_matrix = the camera's projection_matrix (P^T, row-major [16]) or NULL.
+ * pose_state: GSAJ_POSE_STATE_FLOATS device floats owned by the caller:
+ *   [0:16)  W2C row-major (in: current pose; out: Exp(tau) * W2C)      [16:24) Adam m   [24:32) Adam v
+ *   [32]    step count    [33:35) exposure a, b (updated in place)
+ *   [35:51) out world_view_transform = W2C^T     [51:67) out full_proj_transform    [67:70) out camera_center
+ *   [70:76) out tau = [rho, theta] applied       [76] out |tau|     [77] out converged (1.0 / 0.0: |tau| < threshold)
+ * Initialise [0:16) with the pose and zero the rest. */
+#define GSAJ_POSE_STATE_FLOATS 80
+int gsaj_pose_state_floats(void);
+int gsaj_pose_adam_step(const float *dL_dtau, const float *dL_dexposure, float lr_rot, float lr_trans, float lr_exp_a,
+                        float lr_exp_b, float beta1, float beta2, float eps, float converged_threshold,
+                        const float *projection_matrix, float *pose_state, void *stream);
+
 /* ---- dense analytic path (NumPy-path semantics) ------------------ */
 size_t gsaj_dense_workspace_bytes(int N, int W, int H);
 /* N depth-sorted Gaussians: means2D [N,2] (pixels), covs2D [N,2,2], colors [N,3], depths [N], opac [N];

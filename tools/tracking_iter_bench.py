@@ -100,7 +100,52 @@ def main():
                v.grad_mask, v.exposure_a.detach(), v.exposure_b.detach())
         bwd(o["dL_dcolor"], o["dL_ddepth"])
 
+    # D: the whole iteration on the device: render from the tracker's matrices -> loss seeds -> backward -> Adam + update_pose
+    from gsaj import pose_step
+    w2c = np.asarray(cam["viewmatrix"], np.float32).reshape(4, 4).T
+    pt = pose_step.PoseTracker(w2c, cam["projmatrix_raw"], dev)
+    fd = dict(fa)
+
+    def iter_d():
+        fd.update(viewmatrix=pt.viewmatrix, projmatrix=pt.projmatrix, campos=pt.campos)
+        ctx.forward(sync=False, **fd)
+        o = ls(losses.TRACKING, 0.95, 0.01, ctx.color, ctx.depth, ctx.opacity, v.original_image, gt_depth_dev, v.grad_mask,
+               pt.exposure_a, pt.exposure_b)
+        g = ctx.backward(bg=bg, means3D=means, viewmatrix=pt.viewmatrix, projmatrix=pt.projmatrix, projmatrix_raw=proj_raw,
+                         campos=pt.campos, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], dL_dcolor=o["dL_dcolor"],
+                         dL_ddepth=o["dL_ddepth"], sh_degree=3, shs=shs, scales=scales, rotations=rots)
+        pt.step(g["tau_sum"], ls.scalars[3:5])
+
+    # A': the drop-in path with the reference's optimiser step, update_pose and converged read-back (slam_frontend.py:163-193)
+    from utils import pose_utils
+
+    class CamA:
+        pass
+
+    ca = CamA()
+    ca.R, ca.T, ca.device = torch.as_tensor(w2c[:3, :3], device=dev), torch.as_tensor(w2c[:3, 3], device=dev), dev
+    ca.cam_rot_delta = torch.nn.Parameter(torch.zeros(3, device=dev))
+    ca.cam_trans_delta = torch.nn.Parameter(torch.zeros(3, device=dev))
+    ca.update_RT = lambda R, t: (setattr(ca, "R", R), setattr(ca, "T", t))
+    opt = torch.optim.Adam([{"params": [ca.cam_rot_delta], "lr": 0.003}, {"params": [ca.cam_trans_delta], "lr": 0.001},
+                            {"params": [v.exposure_a], "lr": 0.01}, {"params": [v.exposure_b], "lr": 0.01}])
+
+    def iter_a2():
+        opt.zero_grad()
+        color, radii, depth, opacity, n_touched = rast(means3D=means, means2D=means2D, opacities=opac, shs=shs, scales=scales,
+                                                       rotations=rots, theta=ca.cam_rot_delta, rho=ca.cam_trans_delta)
+        loss = slam_utils.get_loss_tracking(cfg, color, depth, opacity, v)
+        loss.backward()
+        with torch.no_grad():
+            opt.step()
+            converged = pose_utils.update_pose(ca)
+        means2D.grad = None
+        return bool(converged)  # the host read-back of the reference loop
+
     ms_a, ms_b, ms_c = timed(iter_a), timed(iter_b), timed(iter_c)
+    ms_a2, ms_d = timed(iter_a2), timed(iter_d)
+    print("full tracking iteration incl. Adam + update_pose: A' drop-in + torch optimiser + converged read-back %.3f ms | "
+          "D all on the device (FrameContext + gsaj_loss_seeds + gsaj_pose_adam_step, no host sync) %.3f ms" % (ms_a2, ms_d))
     print("tracking iteration, cfg2 (%d Gaussians, %dx%d): A drop-in autograd %.3f ms | B FrameContext + torch loss %.3f ms | "
           "C FrameContext + gsaj_loss_seeds %.3f ms" % (P, W, H, ms_a, ms_b, ms_c))
 
