@@ -144,6 +144,20 @@ def main():
 
     ms_a, ms_b, ms_c = timed(iter_a), timed(iter_b), timed(iter_c)
     ms_a2, ms_d = timed(iter_a2), timed(iter_d)
+    # E: iteration D captured once into a HIP graph (all buffers are persistent) and replayed
+    gm8 = v.grad_mask.to(torch.uint8)
+    v.grad_mask = gm8
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        iter_d()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        iter_d()
+    ms_e = timed(graph.replay)
+    print("E: iteration D as one HIP graph replay: %.3f ms" % ms_e)
     print("full tracking iteration incl. Adam + update_pose: A' drop-in + torch optimiser + converged read-back %.3f ms | "
           "D all on the device (FrameContext + gsaj_loss_seeds + gsaj_pose_adam_step, no host sync) %.3f ms" % (ms_a2, ms_d))
     print("tracking iteration, cfg2 (%d Gaussians, %dx%d): A drop-in autograd %.3f ms | B FrameContext + torch loss %.3f ms | "
