@@ -1,0 +1,245 @@
+// knn.hip -- distCUDA2: mean squared distance of every point to its 3 nearest neighbours (gfx950).  SURVEY 8(f)-3.
+//
+// Semantics: reference submodules/simple-knn/simple_knn.cu:45-220 (SimpleKNN::knn) behind simple_knn._C.distCUDA2
+// (spatial.cu): Morton-order the points (10 bits per axis over the bounding box that -- reference quirk, cub init
+// {0,0,0} -- also contains the origin), cut the sorted sequence into boxes, and for every point scan the boxes that can
+// hold one of its 3 nearest neighbours (bound: the 3rd best among its 3 Morton neighbours on either side).  The search
+// is exact, so the result is the 3-NN mean squared distance whatever the box size; points without 3 neighbours keep
+// FLT_MAX terms (-> inf), as in the reference.
+//
+// MI355X design: no host round trips (the reference copies the bounding box to the host twice); one workspace;
+// points gathered into Morton order once so the scans are contiguous; 256-point boxes; a wave (64 consecutive Morton
+// points = spatial neighbours) scans the UNION of the boxes its lanes accept, so a box's points are fetched once per
+// wave through LDS and every lane tests them (a superset of candidates keeps the result exact).
+#include "gsaj_common.h"
+#include <cfloat>
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+#define KNN_BOX 256
+
+struct KnnWS {
+  float *bbox;         // [6] min xyz, max xyz
+  uint32_t *ticket;    // [1]
+  float *bpart;        // [nblk][6]
+  uint32_t *codes, *codes_sorted, *idx, *idx_sorted;
+  float4 *sorted;      // [P] points in Morton order (w unused)
+  float *boxes;        // [nbox][6]
+  void *sort_temp;
+  size_t sort_bytes;
+};
+
+static size_t knn_sort_bytes(int P) {
+  size_t bytes = 0;
+  uint32_t *k = nullptr;
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, k, k, (size_t)P, 0, 30, (hipStream_t)0);
+  return bytes;
+}
+
+static size_t knn_carve(void *base, int P, KnnWS *w) {
+  char *p = (char *)(((uintptr_t)base + 255) & ~(uintptr_t)255);
+  const size_t Pz = (size_t)P, nblk = (Pz + 255) / 256, nbox = (Pz + KNN_BOX - 1) / KNN_BOX;
+  auto take = [&](size_t bytes) { char *r = p; p += (bytes + 255) & ~(size_t)255; return r; };
+  w->bbox = (float *)take(6 * sizeof(float));
+  w->ticket = (uint32_t *)take(sizeof(uint32_t));
+  w->bpart = (float *)take(nblk * 6 * sizeof(float));
+  w->codes = (uint32_t *)take(Pz * 4);
+  w->codes_sorted = (uint32_t *)take(Pz * 4);
+  w->idx = (uint32_t *)take(Pz * 4);
+  w->idx_sorted = (uint32_t *)take(Pz * 4);
+  w->sorted = (float4 *)take(Pz * sizeof(float4));
+  w->boxes = (float *)take(nbox * 6 * sizeof(float));
+  w->sort_bytes = knn_sort_bytes(P);
+  w->sort_temp = take(w->sort_bytes);
+  return (size_t)(p - (char *)base) + 256;
+}
+
+// bounding box incl. the origin (simple_knn.cu:194-203: Reduce with init {0,0,0}); last workgroup combines the partials
+__global__ __launch_bounds__(256) void k_knn_bbox(int P, const float *__restrict__ pts, KnnWS w) {
+  __shared__ float red[6][4];
+  __shared__ bool is_last;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (i < P) {
+    const float x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
+    v[0] = fminf(0.f, x); v[1] = fminf(0.f, y); v[2] = fminf(0.f, z);
+    v[3] = fmaxf(0.f, x); v[4] = fmaxf(0.f, y); v[5] = fmaxf(0.f, z);
+  }
+#pragma unroll
+  for (int c = 0; c < 6; c++)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float t = __shfl_xor(v[c], o);
+      v[c] = c < 3 ? fminf(v[c], t) : fmaxf(v[c], t);
+    }
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int c = 0; c < 6; c++) red[c][threadIdx.x >> 6] = v[c];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+      float s = red[c][0];
+      for (int k = 1; k < 4; k++) s = c < 3 ? fminf(s, red[c][k]) : fmaxf(s, red[c][k]);
+      __hip_atomic_store(&w.bpart[(size_t)blockIdx.x * 6 + c], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    is_last = __hip_atomic_fetch_add(w.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (unsigned b = threadIdx.x; b < gridDim.x; b += 256)
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+      const float t = __hip_atomic_load(&w.bpart[(size_t)b * 6 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      a[c] = c < 3 ? fminf(a[c], t) : fmaxf(a[c], t);
+    }
+#pragma unroll
+  for (int c = 0; c < 6; c++)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float t = __shfl_xor(a[c], o);
+      a[c] = c < 3 ? fminf(a[c], t) : fmaxf(a[c], t);
+    }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int c = 0; c < 6; c++) red[c][threadIdx.x >> 6] = a[c];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+      float s = red[c][0];
+      for (int k = 1; k < 4; k++) s = c < 3 ? fminf(s, red[c][k]) : fmaxf(s, red[c][k]);
+      w.bbox[c] = s;
+    }
+    *w.ticket = 0u;
+  }
+}
+
+__device__ __forceinline__ uint32_t prep_morton(uint32_t x) {  // spread 10 bits to every third position (simple_knn.cu:45-52)
+  x = (x | (x << 16)) & 0x030000FFu;
+  x = (x | (x << 8)) & 0x0300F00Fu;
+  x = (x | (x << 4)) & 0x030C30C3u;
+  x = (x | (x << 2)) & 0x09249249u;
+  return x;
+}
+
+__global__ __launch_bounds__(256) void k_knn_morton(int P, const float *__restrict__ pts, KnnWS w) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= P) return;
+  const float mnx = w.bbox[0], mny = w.bbox[1], mnz = w.bbox[2], mxx = w.bbox[3], mxy = w.bbox[4], mxz = w.bbox[5];
+  const float x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
+  const uint32_t cx = prep_morton((uint32_t)(((x - mnx) / (mxx - mnx)) * 1023.f));
+  const uint32_t cy = prep_morton((uint32_t)(((y - mny) / (mxy - mny)) * 1023.f));
+  const uint32_t cz = prep_morton((uint32_t)(((z - mnz) / (mxz - mnz)) * 1023.f));
+  w.codes[i] = cx | (cy << 1) | (cz << 2);
+  w.idx[i] = (uint32_t)i;
+}
+
+// gather into Morton order + per-box bounds (simple_knn.cu:76-117, 256-point boxes)
+__global__ __launch_bounds__(KNN_BOX) void k_knn_boxes(int P, const float *__restrict__ pts, KnnWS w) {
+  __shared__ float red[6][KNN_BOX / 64];
+  const int i = blockIdx.x * KNN_BOX + threadIdx.x;
+  float v[6] = {FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+  if (i < P) {
+    const size_t src = w.idx_sorted[i];
+    const float x = pts[3 * src], y = pts[3 * src + 1], z = pts[3 * src + 2];
+    w.sorted[i] = make_float4(x, y, z, 0.f);
+    v[0] = x; v[1] = y; v[2] = z; v[3] = x; v[4] = y; v[5] = z;
+  }
+#pragma unroll
+  for (int c = 0; c < 6; c++)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float t = __shfl_xor(v[c], o);
+      v[c] = c < 3 ? fminf(v[c], t) : fmaxf(v[c], t);
+    }
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int c = 0; c < 6; c++) red[c][threadIdx.x >> 6] = v[c];
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int c = threadIdx.x;
+    float s = red[c][0];
+    for (int k = 1; k < KNN_BOX / 64; k++) s = c < 3 ? fminf(s, red[c][k]) : fmaxf(s, red[c][k]);
+    w.boxes[(size_t)blockIdx.x * 6 + c] = s;
+  }
+}
+
+__device__ __forceinline__ void k_best3(float d, float &b0, float &b1, float &b2) {  // simple_knn.cu:134-147
+  if (b0 > d) { const float t = b0; b0 = d; d = t; }
+  if (b1 > d) { const float t = b1; b1 = d; d = t; }
+  if (b2 > d) { b2 = d; }
+}
+
+__global__ __launch_bounds__(64) void k_knn_mean_dist(int P, KnnWS w, float *__restrict__ out) {
+  __shared__ float4 stage[KNN_BOX];
+  const int lane = threadIdx.x;
+  const int i = blockIdx.x * 64 + lane;
+  const bool live = i < P;
+  const float4 me = live ? w.sorted[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  float b0 = FLT_MAX, b1 = FLT_MAX, b2 = FLT_MAX;
+  if (live) {
+    for (int j = max(0, i - 3); j <= min(P - 1, i + 3); j++) {
+      if (j == i) continue;
+      const float4 q = w.sorted[j];
+      const float dx = q.x - me.x, dy = q.y - me.y, dz = q.z - me.z;
+      k_best3(dx * dx + dy * dy + dz * dz, b0, b1, b2);
+    }
+  }
+  const float reject = b2;  // an upper bound of the true 3rd-nearest distance (simple_knn.cu:165)
+  b0 = FLT_MAX; b1 = FLT_MAX; b2 = FLT_MAX;
+  const int nbox = (P + KNN_BOX - 1) / KNN_BOX;
+  for (int b = 0; b < nbox; b++) {
+    const float *bx = w.boxes + (size_t)b * 6;
+    float ddx = 0.f, ddy = 0.f, ddz = 0.f;  // distBoxPoint, simple_knn.cu:119-130
+    if (me.x < bx[0] || me.x > bx[3]) ddx = fminf(fabsf(me.x - bx[0]), fabsf(me.x - bx[3]));
+    if (me.y < bx[1] || me.y > bx[4]) ddy = fminf(fabsf(me.y - bx[1]), fabsf(me.y - bx[4]));
+    if (me.z < bx[2] || me.z > bx[5]) ddz = fminf(fabsf(me.z - bx[2]), fabsf(me.z - bx[5]));
+    const float dist = ddx * ddx + ddy * ddy + ddz * ddz;
+    const bool want = live && !(dist > reject || dist > b2);
+    if (__builtin_amdgcn_ballot_w64(want) == 0ull) continue;  // wave-uniform: scan the union of the lanes' boxes
+    const int base = b * KNN_BOX, cnt = min(KNN_BOX, P - base);
+    __builtin_amdgcn_wave_barrier();
+    for (int t = lane; t < cnt; t += 64) stage[t] = w.sorted[base + t];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int t = 0; t < cnt; t++) {
+      const float4 q = stage[t];
+      const float dx = q.x - me.x, dy = q.y - me.y, dz = q.z - me.z;
+      const float d = dx * dx + dy * dy + dz * dz;
+      if (base + t != i) k_best3(d, b0, b1, b2);
+    }
+  }
+  if (live) out[w.idx_sorted[i]] = (b0 + b1 + b2) / 3.0f;
+}
+
+extern "C" size_t gsaj_dist2_workspace_bytes(int P) {
+  if (P <= 0) return 512;
+  KnnWS w;
+  return knn_carve(nullptr, P, &w);
+}
+
+extern "C" int gsaj_dist2(int P, const float *points, float *mean_dists, void *knn_ws, void *stream) {
+  if (P < 0 || (P > 0 && (!points || !mean_dists || !knn_ws))) {
+    gsaj_set_error("gsaj_dist2: invalid argument (P=%d)", P);
+    return GSAJ_ERR_INVALID_ARGUMENT;
+  }
+  if (P == 0) return GSAJ_OK;
+  hipStream_t s = (hipStream_t)stream;
+  KnnWS w;
+  knn_carve(knn_ws, P, &w);
+  GSAJ_HIP_CHECK(hipMemsetAsync(w.ticket, 0, sizeof(uint32_t), s));
+  const unsigned nblk = (unsigned)((P + 255) / 256), nbox = (unsigned)((P + KNN_BOX - 1) / KNN_BOX);
+  hipLaunchKernelGGL(k_knn_bbox, dim3(nblk), dim3(256), 0, s, P, points, w);
+  hipLaunchKernelGGL(k_knn_morton, dim3(nblk), dim3(256), 0, s, P, points, w);
+  size_t bytes = w.sort_bytes;
+  GSAJ_HIP_CHECK(rocprim::radix_sort_pairs(w.sort_temp, bytes, w.codes, w.codes_sorted, w.idx, w.idx_sorted, (size_t)P, 0, 30, s));
+  hipLaunchKernelGGL(k_knn_boxes, dim3(nbox), dim3(KNN_BOX), 0, s, P, points, w);
+  hipLaunchKernelGGL(k_knn_mean_dist, dim3((P + 63) / 64), dim3(64), 0, s, P, w, mean_dists);
+  GSAJ_HIP_CHECK(hipGetLastError());
+  return GSAJ_OK;
+}

@@ -46,6 +46,8 @@ SIGNATURES = {
     "gsaj_dense_render": (c_int, [c_int, c_int, c_int] + [P] * 5 + [P, P, P]),
     "gsaj_pose_jacobians": (c_int, [c_int, P, P, P, c_double, c_double, c_int, c_int, P, P, P]),
     "gsaj_dense_tau": (c_int, [c_int, c_int, c_int] + [P] * 11 + [P, P, P]),
+    "gsaj_dist2_workspace_bytes": (c_size_t, [c_int]),
+    "gsaj_dist2": (c_int, [c_int, P, P, P, P]),
     "gsaj_pose_state_floats": (c_int, []),
     "gsaj_pose_adam_step": (c_int, [P, P] + [c_float] * 8 + [P, P, P]),
     "gsaj_loss_workspace_bytes": (c_size_t, [c_int, c_int]),

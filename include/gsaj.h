@@ -206,6 +206,14 @@ int gsaj_pose_adam_step(const float *dL_dtau, const float *dL_dexposure, float l
                         float lr_exp_b, float beta1, float beta2, float eps, float converged_threshold,
                         const float *projection_matrix, float *pose_state, void *stream);
 
+/* ---- distCUDA2 -------------------------------------------------------------------
+ * simple_knn._C.distCUDA2 (reference submodules/simple-knn/simple_knn.cu:45-220, spatial.cu): for P points
+ * [P,3] the mean of the squared distances to the 3 nearest other points -> mean_dists [P].  Exact search;
+ * fewer than 3 neighbours leaves FLT_MAX terms (-> inf) as in the reference.  No host synchronisation.
+ * knn_ws: gsaj_dist2_workspace_bytes(P) bytes. */
+size_t gsaj_dist2_workspace_bytes(int P);
+int gsaj_dist2(int P, const float *points, float *mean_dists, void *knn_ws, void *stream);
+
 /* ---- dense analytic path (NumPy-path semantics) ------------------ */
 size_t gsaj_dense_workspace_bytes(int N, int W, int H);
 /* N depth-sorted Gaussians: means2D [N,2] (pixels), covs2D [N,2,2], colors [N,3], depths [N], opac [N];

@@ -1,0 +1,47 @@
+"""GPU: distCUDA2 (gsaj_dist2) against brute force; the overlay package keeps the reference's import path."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(p):
+    import torch
+    from simple_knn._C import distCUDA2
+
+    return distCUDA2(torch.as_tensor(p, dtype=torch.float32, device="cuda:0")).cpu().numpy()
+
+
+@pytest.mark.parametrize("n,kind", [(1, "u"), (2, "u"), (3, "u"), (4, "u"), (257, "u"), (5000, "u"), (5000, "clustered"), (4096, "plane"),
+                                    (3000, "dups"), (20000, "depthmap")])
+def test_dist2_matches_brute_force(n, kind):
+    from oracle import knn_oracle
+
+    rng = np.random.default_rng(n)
+    if kind == "u":
+        p = rng.uniform(-2, 3, (n, 3))
+    elif kind == "clustered":
+        p = rng.normal(size=(n, 3)) * 0.01 + rng.integers(0, 5, (n, 1)) * 1.0
+    elif kind == "plane":
+        p = np.concatenate([rng.uniform(0.5, 1, (n, 2)), np.full((n, 1), 2.0)], axis=1)   # degenerate z extent, origin outside
+    elif kind == "dups":
+        p = np.repeat(rng.uniform(-1, 1, (n // 3, 3)), 3, axis=0)                           # exact duplicates: zero distances
+    else:  # back-projected depth image, the actual use (gaussian_model.py:246)
+        u, v = np.meshgrid(np.arange(200), np.arange(n // 200))
+        z = 1.5 + 0.3 * np.sin(u / 17.0) + 0.2 * np.cos(v / 11.0) + rng.normal(0, 0.002, u.shape)
+        p = np.stack([(u - 100) / 300.0 * z, (v - 50) / 300.0 * z, z], axis=-1).reshape(-1, 3)
+    p = p.astype(np.float32)
+    got, want = _run(p), knn_oracle.dist2(p)
+    if n < 4:  # missing neighbours contribute FLT_MAX terms: inf for n <= 2, ~FLT_MAX / 3 for n = 3 (as in the reference)
+        assert (np.isinf(want) == np.isinf(got)).all() and (got > 1e37).all()
+        np.testing.assert_allclose(got[np.isfinite(got)], want[np.isfinite(want)], rtol=1e-6)
+        return
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-12)
+
+
+def test_dist2_is_invariant_to_point_order():
+    rng = np.random.default_rng(5)
+    p = rng.uniform(-1, 1, (3000, 3)).astype(np.float32)
+    perm = rng.permutation(3000)
+    a, b = _run(p), _run(p[perm])
+    np.testing.assert_array_equal(a[perm], b)   # exact search: bitwise the same whatever the Morton tie-breaking
