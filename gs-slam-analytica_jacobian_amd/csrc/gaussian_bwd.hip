@@ -97,7 +97,8 @@ __device__ __forceinline__ float3 sh_backward(int deg, float3 pos, float3 campos
 // SHW = 3*M as a compile-time constant (0: runtime) -- the staging loops divide by it per element
 template <int SHW>
 __global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g, uint32_t *__restrict__ counters,
-                                                           const float4 *__restrict__ inst_grad) {
+                                                           const float4 *__restrict__ inst_grad,
+                                                           const uint8_t *__restrict__ reached) {
   extern __shared__ float sh_lds[];  // [2][GB_BLOCK][3M+1]: SH coefficients in, dL/dSH out (padded rows)
   __shared__ uint32_t s_ticket;
   if (counters[4]) return;  // aborted async frame
@@ -169,8 +170,11 @@ __global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g
 #pragma unroll
       for (int w = 0; w < 4; w++) {
         const uint32_t r = lo + (uint32_t)(w * GB_BLOCK + tid);
-        const float4 *src = inst_grad + (size_t)(r < hi ? r : lo) * REC_F4;
-        a[w][0] = src[0]; a[w][1] = src[1]; a[w][2] = src[2];
+        a[w][0] = a[w][1] = a[w][2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < hi && reached[r]) {  // rows the reverse compositor never wrote are zero by definition
+          const float4 *src = inst_grad + (size_t)r * REC_F4;
+          a[w][0] = src[0]; a[w][1] = src[1]; a[w][2] = src[2];
+        }
       }
 #pragma unroll
       for (int w = 0; w < 4; w++) {
@@ -425,11 +429,11 @@ int launch_gaussian_backward(const BwdParams &p, const GeomWS &g, const BinWS &b
     GsajProfScope ps(ST_GAUSSIAN_BWD, s);
     const size_t lds = p.shs ? sizeof(float) * 2 * GB_BLOCK * (3 * (size_t)p.M + 1) : 0;
     switch (p.shs ? p.M : -1) {
-      case 1: hipLaunchKernelGGL(k_gaussian_bwd<3>, dim3(nblk), dim3(GB_BLOCK), lds, s, p, g, im.counters, b.inst_grad); break;
-      case 4: hipLaunchKernelGGL(k_gaussian_bwd<12>, dim3(nblk), dim3(GB_BLOCK), lds, s, p, g, im.counters, b.inst_grad); break;
-      case 9: hipLaunchKernelGGL(k_gaussian_bwd<27>, dim3(nblk), dim3(GB_BLOCK), lds, s, p, g, im.counters, b.inst_grad); break;
-      case 16: hipLaunchKernelGGL(k_gaussian_bwd<48>, dim3(nblk), dim3(GB_BLOCK), lds, s, p, g, im.counters, b.inst_grad); break;
-      default: hipLaunchKernelGGL(k_gaussian_bwd<0>, dim3(nblk), dim3(GB_BLOCK), lds, s, p, g, im.counters, b.inst_grad); break;
+      case 1: hipLaunchKernelGGL(k_gaussian_bwd<3>, dim3(nblk), dim3(GB_BLOCK), lds, s, p, g, im.counters, b.inst_grad, b.reached); break;
+      case 4: hipLaunchKernelGGL(k_gaussian_bwd<12>, dim3(nblk), dim3(GB_BLOCK), lds, s, p, g, im.counters, b.inst_grad, b.reached); break;
+      case 9: hipLaunchKernelGGL(k_gaussian_bwd<27>, dim3(nblk), dim3(GB_BLOCK), lds, s, p, g, im.counters, b.inst_grad, b.reached); break;
+      case 16: hipLaunchKernelGGL(k_gaussian_bwd<48>, dim3(nblk), dim3(GB_BLOCK), lds, s, p, g, im.counters, b.inst_grad, b.reached); break;
+      default: hipLaunchKernelGGL(k_gaussian_bwd<0>, dim3(nblk), dim3(GB_BLOCK), lds, s, p, g, im.counters, b.inst_grad, b.reached); break;
     }
   }
   GSAJ_HIP_CHECK(hipGetLastError());

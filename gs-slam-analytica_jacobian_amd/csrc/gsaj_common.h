@@ -115,6 +115,7 @@ struct BinWS {  // reference: BinningState, rasterizer_impl.h:55-66
   uint32_t *point_list;     // [R] sorted Gaussian ids
   float4 *records;          // [R*3]
   float4 *inst_grad;        // [R*3] per-instance partial gradients (backward), indexed by emission slot
+  uint8_t *reached;         // [R] by emission slot: 1 = the reverse compositor wrote that row, 0 = no pixel of the tile got that far
   char *sort_temp;
   size_t sort_temp_bytes;
 };
@@ -130,6 +131,7 @@ static inline size_t bin_carve(char *base, size_t R, size_t sort_temp_bytes, Bin
   CARVE(point_list, uint32_t, Rn);
   CARVE(records, float4, Rn * REC_F4);
   CARVE(inst_grad, float4, Rn * REC_F4);
+  CARVE(reached, uint8_t, Rn);
   CARVE(sort_temp, char, sort_temp_bytes);
   if (g) g->sort_temp_bytes = sort_temp_bytes;
   return off;

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                                                     const uint32_t *__restrict__ n_contrib,
                                                     const float *__restrict__ dL_dpix,
                                                     const float *__restrict__ dL_dpix_depth,
-                                                    float4 *__restrict__ inst_grad,
+                                                    float4 *__restrict__ inst_grad, uint8_t *__restrict__ reached,
                                                     const uint32_t *__restrict__ counters) {
   __shared__ float4 rec[BWD_ROUND * REC_F4];
   __shared__ __attribute__((aligned(16))) float acc[4 * ACC_C * ACC_STRIDE];  // [wave][partial][entry]
@@ -96,13 +96,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
   const float p2_py = qy0 + (float)p2_row;
 
   uint32_t hi = range.x + bmax;  // exclusive sorted position
-  // entries [hi, range.y) were never reached by any pixel of the tile: their partials are zero
-  for (uint32_t k = hi + tid; k < range.y; k += 256) {
-    float4 *dst = inst_grad + (size_t)__float_as_uint(records[(size_t)k * REC_F4 + 2].w) * REC_F4;
-    dst[0] = make_float4(0.f, 0.f, 0.f, 0.f);
-    dst[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-    dst[2] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
+  // entries [hi, range.y) were never reached by any pixel of the tile: their partials are zero.  Only a one-byte
+  // flag says so (opaque scenes leave most of a long list unreached: 48-byte zero rows would be most of the traffic)
+  for (uint32_t k = hi + tid; k < range.y; k += 256) reached[__float_as_uint(records[(size_t)k * REC_F4 + 2].w)] = 0;
 
   while (hi > range.x) {
     const uint32_t lo = (hi - range.x > BWD_ROUND) ? hi - BWD_ROUND : range.x;
@@ -245,10 +241,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
       }
       const float4 s0 = make_float4(t[0], t[1], t[2], t[3]), s1 = make_float4(t[4], t[5], t[6], t[7]),
                    s2 = make_float4(t[8], t[9], 0.f, 0.f);
-      float4 *dst = inst_grad + (size_t)__float_as_uint(rec[tid * REC_F4 + 2].w) * REC_F4;  // emission slot
+      const uint32_t emit = __float_as_uint(rec[tid * REC_F4 + 2].w);  // emission slot
+      float4 *dst = inst_grad + (size_t)emit * REC_F4;
       dst[0] = s0;
       dst[1] = s1;
       dst[2] = s2;
+      reached[emit] = 1;
     }
     __syncthreads();
     hi = lo;
@@ -262,7 +260,7 @@ int launch_render_backward(int R, int W, int H, int grid_x, int grid_y, const fl
   {
     GsajProfScope ps(ST_RENDER_BWD, s);
     hipLaunchKernelGGL(k_render_bwd, dim3(grid_x * grid_y), dim3(256), 0, s, W, H, grid_x, im.ranges, b.records, bg,
-                       im.final_T, im.n_contrib, dL_dpix, dL_dpix_depth, b.inst_grad, im.counters);
+                       im.final_T, im.n_contrib, dL_dpix, dL_dpix_depth, b.inst_grad, b.reached, im.counters);
   }
   GSAJ_HIP_CHECK(hipGetLastError());
   return GSAJ_OK;
