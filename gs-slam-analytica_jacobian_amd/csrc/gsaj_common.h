@@ -87,6 +87,7 @@ struct ImageWS {  // reference: ImageState, rasterizer_impl.h:46-53
   uint32_t *tile_cursor;  // [tiles*TILE_REP]        -+
   uint32_t *tile_offset;  // [tiles*TILE_REP + 1] exclusive scan of tile_count (tile-major)
   uint32_t *sticky;       // [16] never zeroed by a forward: [0] number of aborted async forwards
+  uint32_t *finish_list;  // [tiles] tile indices in the order their forward workgroups finished (counters[6] = how many)
   size_t zero_bytes;      // bytes from counters to the end of tile_cursor
 };
 
@@ -105,6 +106,7 @@ static inline __host__ __device__ size_t image_carve(char *base, int W, int H, I
   if (g) g->zero_bytes = off - z0;
   CARVE(tile_offset, uint32_t, tiles * TILE_REP + 1);
   CARVE(sticky, uint32_t, 16);
+  CARVE(finish_list, uint32_t, tiles);
   return off;
 }
 

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                                                     const uint32_t *__restrict__ n_contrib,
                                                     const float *__restrict__ dL_dpix,
                                                     const float *__restrict__ dL_dpix_depth,
-                                                    float4 *__restrict__ inst_grad, uint8_t *__restrict__ reached,
+                                                    float4 *__restrict__ inst_grad, uint8_t *__restrict__ reached, const uint32_t *__restrict__ finish_list,
                                                     const uint32_t *__restrict__ counters) {
   __shared__ float4 rec[BWD_ROUND * REC_F4];
   __shared__ __attribute__((aligned(16))) float acc[4 * ACC_C * ACC_STRIDE];  // [wave][partial][entry]
@@ -57,7 +57,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   float2 *wu = wu_all + wave * SLOTS * WU_STRIDE;
   float4 *seed = seed_all + wave * 64;
-  const int tile = blockIdx.x;
+  // longest-running forward tiles first (clamped: a stale list must not become an out-of-range tile)
+  const int tile = (int)min(finish_list[gridDim.x - 1 - blockIdx.x], gridDim.x - 1);
   const int ty = tile / gx, tx = tile - ty * gx;
   const int px = tx * TILE + (wave & 1) * 8 + (lane & 7);
   const int py = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
@@ -260,7 +261,7 @@ int launch_render_backward(int R, int W, int H, int grid_x, int grid_y, const fl
   {
     GsajProfScope ps(ST_RENDER_BWD, s);
     hipLaunchKernelGGL(k_render_bwd, dim3(grid_x * grid_y), dim3(256), 0, s, W, H, grid_x, im.ranges, b.records, bg,
-                       im.final_T, im.n_contrib, dL_dpix, dL_dpix_depth, b.inst_grad, b.reached, im.counters);
+                       im.final_T, im.n_contrib, dL_dpix, dL_dpix_depth, b.inst_grad, b.reached, im.finish_list, im.counters);
   }
   GSAJ_HIP_CHECK(hipGetLastError());
   return GSAJ_OK;

@@ -25,12 +25,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                                                     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                                                     float *__restrict__ out_color, float *__restrict__ out_depth,
                                                     float *__restrict__ out_opacity, int *__restrict__ n_touched,
-                                                    const uint32_t *__restrict__ counters) {
+                                                    uint32_t *__restrict__ counters, uint32_t *__restrict__ finish_list) {
   // Each wave (one 8x8 quadrant) walks the tile list on its own: private 64-record staging area, no
   // workgroup barrier anywhere, so a quadrant never waits for a slower neighbour.  The four waves of a
   // tile read the same records; the repeats are served by L1/L2.
   __shared__ float4 rec_all[4 * (FWD_CHUNK + FWD_PAD) * REC_F4];
+  __shared__ uint32_t waves_done;
   if (counters[4]) return;  // aborted async frame
+  if (threadIdx.x == 0) waves_done = 0u;
+  __syncthreads();  // the only workgroup barrier: the counter is initialised before any wave can finish
   GSAJ_TRACE_BEGIN(fwd)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   float4 *rec = rec_all + wave * (FWD_CHUNK + FWD_PAD) * REC_F4;
@@ -159,6 +162,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     out_depth[pid] = Dp;
     out_opacity[pid] = 1.f - T;
   }
+  // Tiles are listed in the order their workgroups finish: the reverse compositor walks that list backwards, so the
+  // tiles that kept a quadrant busy longest (deepest last contributor = most backward work) start first there.
+  if (lane == 0 && atomicAdd(&waves_done, 1u) == 3u) finish_list[atomicAdd(&counters[6], 1u)] = (uint32_t)tile;
   GSAJ_TRACE_END(fwd)
 }
 
@@ -167,7 +173,7 @@ int launch_render_forward(int W, int H, int grid_x, int grid_y, const float *bg,
   {
     GsajProfScope ps(ST_RENDER_FWD, s);
     hipLaunchKernelGGL(k_render_fwd, dim3(grid_x * grid_y), dim3(256), 0, s, W, H, grid_x, im.ranges, b.records, bg,
-                     im.final_T, im.n_contrib, out_color, out_depth, out_opacity, n_touched, im.counters);
+                     im.final_T, im.n_contrib, out_color, out_depth, out_opacity, n_touched, im.counters, im.finish_list);
   }
   GSAJ_HIP_CHECK(hipGetLastError());
   return GSAJ_OK;
