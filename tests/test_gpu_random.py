@@ -110,3 +110,56 @@ def test_full_size_properties_cfg2():
     scale = float(b3.abs().max())
     assert float((b3 - (2.0 * b1 - 0.5 * b2)).abs().max()) < 2e-4 * scale
     assert float((t3 - (2.0 * t1 - 0.5 * t2)).abs().max()) < 2e-4 * float(t3.abs().max())
+
+
+@pytest.mark.parametrize("wl", ["cfg3", "cfg5"])
+def test_large_config_properties_without_oracle(wl):
+    """cfg3 (300 000 Gaussians, 1200x680) and cfg5 (10^6 Gaussians, 1280x720): too large for the CPU oracle inside a test,
+    so only properties that need no oracle -- instance count = sum of tiles touched, every tile list sorted by (depth, id),
+    opacity + final_T = 1, n_contrib within the list, bit-identical repeat, backward linear in the pixel seeds."""
+    import torch
+    from gsaj import rasterizer as C
+    from gsaj.rasterizer import FrameContext
+
+    cam, sc = syn.config_scene(wl)
+    P, W, H, M = sc["means3D"].shape[0], cam["W"], cam["H"], sc["shs"].shape[1]
+    deg = int(round(M ** 0.5)) - 1
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)  # noqa: E731
+    ctx = FrameContext(P, W, H, M, dev)
+    fa = dict(bg=torch.zeros(3, device=dev), means3D=t(sc["means3D"]), opacities=t(sc["opacities"]), viewmatrix=t(cam["viewmatrix"]),
+              projmatrix=t(cam["projmatrix"]), campos=t(cam["campos"]), tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], sh_degree=deg,
+              shs=t(sc["shs"]), scales=t(sc["scales"]), rotations=t(sc["rotations"]))
+    ctx.forward(**fa)
+    R, longest = ctx.status()
+    dbg = C.debug_export(P, R, W, H, ctx.geom, ctx.binning, ctx.img)
+    assert R == int(dbg["tiles_touched"].long().sum()) and longest <= 4096
+    pl, rg = dbg["point_list"].long(), dbg["ranges"].long()
+    d = dbg["depths"][pl]
+    tile_of = torch.repeat_interleave(torch.arange(rg.shape[0], device=dev), rg[:, 1] - rg[:, 0])
+    same = tile_of[1:] == tile_of[:-1]
+    assert bool(((d[1:] > d[:-1]) | ((d[1:] == d[:-1]) & (pl[1:] > pl[:-1])) | ~same).all())
+    assert int((rg[:, 1] - rg[:, 0]).max()) == longest
+    assert torch.allclose(ctx.opacity[0] + dbg["final_T"], torch.ones_like(dbg["final_T"]), atol=1e-6)
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    per_pixel_len = (rg[:, 1] - rg[:, 0]).view(gy, gx).repeat_interleave(16, 0).repeat_interleave(16, 1)[:H, :W]
+    assert int((dbg["n_contrib"].long() > per_pixel_len).sum()) == 0
+    color1 = ctx.color.clone()
+    s1c, s1d = hp.seeds(cam, seed=21)
+    s2c, s2d = hp.seeds(cam, seed=22)
+
+    def bwd(c, dd):
+        g = ctx.backward(bg=fa["bg"], means3D=fa["means3D"], viewmatrix=fa["viewmatrix"], projmatrix=fa["projmatrix"],
+                         projmatrix_raw=t(cam["projmatrix_raw"]), campos=fa["campos"], tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"],
+                         dL_dcolor=t(c), dL_ddepth=t(dd), sh_degree=deg, shs=fa["shs"], scales=fa["scales"], rotations=fa["rotations"])
+        return ctx.bucket.clone(), g["tau_sum"].clone()
+
+    b1, t1 = bwd(s1c, s1d)
+    b2, t2 = bwd(s2c, s2d)
+    b3, t3 = bwd(s1c + 3.0 * s2c, s1d + 3.0 * s2d)
+    ctx.forward(**fa)
+    assert torch.equal(ctx.color, color1)
+    b1b, t1b = bwd(s1c, s1d)
+    assert torch.equal(b1, b1b) and torch.equal(t1, t1b)
+    assert float((b3 - (b1 + 3.0 * b2)).abs().max()) < 3e-4 * float(b3.abs().max())
+    assert float((t3 - (t1 + 3.0 * t2)).abs().max()) < 3e-4 * float(t3.abs().max())
