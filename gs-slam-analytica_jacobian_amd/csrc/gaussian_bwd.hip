@@ -32,10 +32,12 @@ __device__ __forceinline__ float3 dnormvdv(float3 v, float3 dv) {
   return o;
 }
 
-// SH backward: writes dL/dsh, returns dL/dmean through the view direction.
-__device__ __forceinline__ float3 sh_backward(int deg, float3 pos, float3 campos, const float *__restrict__ sh,
-                                              const uint8_t *__restrict__ clamped, float3 gcol,
-                                              float *__restrict__ dL_dsh) {
+// SH backward IN PLACE: `sh` holds this Gaussian's coefficients [M][3] on entry and dL/dsh on return (zeros above the
+// active degree); within a band every coefficient is read before the band's gradients overwrite it.  Returns dL/dmean
+// through the view direction.
+__device__ __forceinline__ float3 sh_backward(int deg, int M, float3 pos, float3 campos, float *sh,
+                                              const uint8_t *__restrict__ clamped, float3 gcol) {
+  float *dL_dsh = sh;
   const float3 dorig = make_float3(pos.x - campos.x, pos.y - campos.y, pos.z - campos.z);
   const float len = sqrtf(dorig.x * dorig.x + dorig.y * dorig.y + dorig.z * dorig.z);
   const float x = dorig.x / len, y = dorig.y / len, z = dorig.z / len;
@@ -51,27 +53,24 @@ __device__ __forceinline__ float3 sh_backward(int deg, float3 pos, float3 campos
   }
   OUT(0, bSH_C0)
   if (deg > 0) {
-    OUT(1, -bSH_C1 * y) OUT(2, bSH_C1 * z) OUT(3, -bSH_C1 * x)
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
       dx[ch] = -bSH_C1 * SH(3, ch);
       dy[ch] = -bSH_C1 * SH(1, ch);
       dz[ch] = bSH_C1 * SH(2, ch);
     }
+    OUT(1, -bSH_C1 * y) OUT(2, bSH_C1 * z) OUT(3, -bSH_C1 * x)
     if (deg > 1) {
       const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-      OUT(4, bSH_C2[0] * xy) OUT(5, bSH_C2[1] * yz) OUT(6, bSH_C2[2] * (2.f * zz - xx - yy))
-      OUT(7, bSH_C2[3] * xz) OUT(8, bSH_C2[4] * (xx - yy))
 #pragma unroll
       for (int ch = 0; ch < 3; ch++) {
         dx[ch] += bSH_C2[0] * y * SH(4, ch) + bSH_C2[2] * 2.f * -x * SH(6, ch) + bSH_C2[3] * z * SH(7, ch) + bSH_C2[4] * 2.f * x * SH(8, ch);
         dy[ch] += bSH_C2[0] * x * SH(4, ch) + bSH_C2[1] * z * SH(5, ch) + bSH_C2[2] * 2.f * -y * SH(6, ch) + bSH_C2[4] * 2.f * -y * SH(8, ch);
         dz[ch] += bSH_C2[1] * y * SH(5, ch) + bSH_C2[2] * 2.f * 2.f * z * SH(6, ch) + bSH_C2[3] * x * SH(7, ch);
       }
+      OUT(4, bSH_C2[0] * xy) OUT(5, bSH_C2[1] * yz) OUT(6, bSH_C2[2] * (2.f * zz - xx - yy))
+      OUT(7, bSH_C2[3] * xz) OUT(8, bSH_C2[4] * (xx - yy))
       if (deg > 2) {
-        OUT(9, bSH_C3[0] * y * (3.f * xx - yy)) OUT(10, bSH_C3[1] * xy * z) OUT(11, bSH_C3[2] * y * (4.f * zz - xx - yy))
-        OUT(12, bSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)) OUT(13, bSH_C3[4] * x * (4.f * zz - xx - yy))
-        OUT(14, bSH_C3[5] * z * (xx - yy)) OUT(15, bSH_C3[6] * x * (xx - 3.f * yy))
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
           dx[ch] += (bSH_C3[0] * SH(9, ch) * 3.f * 2.f * xy + bSH_C3[1] * SH(10, ch) * yz + bSH_C3[2] * SH(11, ch) * -2.f * xy +
@@ -84,11 +83,15 @@ __device__ __forceinline__ float3 sh_backward(int deg, float3 pos, float3 campos
                      bSH_C3[3] * SH(12, ch) * 3.f * (2.f * zz - xx - yy) + bSH_C3[4] * SH(13, ch) * 4.f * 2.f * xz +
                      bSH_C3[5] * SH(14, ch) * (xx - yy));
         }
+        OUT(9, bSH_C3[0] * y * (3.f * xx - yy)) OUT(10, bSH_C3[1] * xy * z) OUT(11, bSH_C3[2] * y * (4.f * zz - xx - yy))
+        OUT(12, bSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)) OUT(13, bSH_C3[4] * x * (4.f * zz - xx - yy))
+        OUT(14, bSH_C3[5] * z * (xx - yy)) OUT(15, bSH_C3[6] * x * (xx - 3.f * yy))
       }
     }
   }
 #undef SH
 #undef OUT
+  for (int k = (deg + 1) * (deg + 1) * 3; k < 3 * M; k++) dL_dsh[k] = 0.f;  // coefficients above the active degree
   const float3 ddir = make_float3(dx[0] * g[0] + dx[1] * g[1] + dx[2] * g[2], dy[0] * g[0] + dy[1] * g[1] + dy[2] * g[2],
                                   dz[0] * g[0] + dz[1] * g[1] + dz[2] * g[2]);
   return dnormvdv(dorig, ddir);
@@ -99,13 +102,13 @@ template <int SHW>
 __global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g, uint32_t *__restrict__ counters,
                                                            const float4 *__restrict__ inst_grad,
                                                            const uint8_t *__restrict__ reached) {
-  extern __shared__ float sh_lds[];  // [2][GB_BLOCK][3M+1]: SH coefficients in, dL/dSH out (padded rows)
+  extern __shared__ float sh_lds[];  // [GB_BLOCK][3M+1]: SH coefficients in, overwritten in place by dL/dSH (padded rows)
   __shared__ uint32_t s_ticket;
   if (counters[4]) return;  // aborted async frame
   const int tid = threadIdx.x;
   const int idx = blockIdx.x * GB_BLOCK + tid;
   const int shw = SHW > 0 ? SHW : 3 * p.M, shs_stride = shw + 1;
-  float *sh_in = sh_lds, *sh_out = sh_lds + GB_BLOCK * shs_stride;
+  float *sh_io = sh_lds;
   // ---- 0. every input of this Gaussian is requested up front (this stage is latency-bound: one wave
   //         per SIMD, so the loads must be in flight together, not one s_waitcnt apart) ----
   const int radius = idx < p.P ? p.radii[idx] : 0;
@@ -144,8 +147,7 @@ __global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g
         const int e = e0 + b * GB_BLOCK + tid;
         if (e < count) {
           const int gi = e / shw, k = e - gi * shw;
-          sh_in[gi * shs_stride + k] = v[b];
-          sh_out[gi * shs_stride + k] = 0.f;
+          sh_io[gi * shs_stride + k] = v[b];
         }
       }
     }
@@ -313,8 +315,7 @@ __global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g
     // ---- 5. colour -> SH, view direction -> mean3D, tau ----
     if (p.shs) {
       const float3 cam = make_float3(p.campos[0], p.campos[1], p.campos[2]);
-      const float3 dmean = sh_backward(p.D, mean, cam, sh_in + tid * shs_stride, cl, gcol,
-                                       sh_out + tid * shs_stride);
+      const float3 dmean = sh_backward(p.D, p.M, mean, cam, sh_io + tid * shs_stride, cl, gcol);
       gm.x += dmean.x; gm.y += dmean.y; gm.z += dmean.z;
       tau[0] -= dmean.x; tau[1] -= dmean.y; tau[2] -= dmean.z;
     }
@@ -413,12 +414,15 @@ __global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g
   }
   // dL/dSH block: coalesced store (rows of culled Gaussians and coefficients above the active degree are zero)
   if (p.shs) {
+    if (!vis) {
+      for (int k = 0; k < shw; k++) sh_io[tid * shs_stride + k] = 0.f;
+    }
     __syncthreads();
     const size_t base = (size_t)blockIdx.x * GB_BLOCK * shw;
     const int count = min(GB_BLOCK, p.P - blockIdx.x * GB_BLOCK) * shw;
     for (int e = tid; e < count; e += GB_BLOCK) {
       const int gi = e / shw, k = e - gi * shw;
-      p.dL_dsh[base + e] = sh_out[gi * shs_stride + k];
+      p.dL_dsh[base + e] = sh_io[gi * shs_stride + k];
     }
   }
 }
@@ -427,7 +431,7 @@ int launch_gaussian_backward(const BwdParams &p, const GeomWS &g, const BinWS &b
   const int nblk = (p.P + GB_BLOCK - 1) / GB_BLOCK;
   {
     GsajProfScope ps(ST_GAUSSIAN_BWD, s);
-    const size_t lds = p.shs ? sizeof(float) * 2 * GB_BLOCK * (3 * (size_t)p.M + 1) : 0;
+    const size_t lds = p.shs ? sizeof(float) * GB_BLOCK * (3 * (size_t)p.M + 1) : 0;
     switch (p.shs ? p.M : -1) {
       case 1: hipLaunchKernelGGL(k_gaussian_bwd<3>, dim3(nblk), dim3(GB_BLOCK), lds, s, p, g, im.counters, b.inst_grad, b.reached); break;
       case 4: hipLaunchKernelGGL(k_gaussian_bwd<12>, dim3(nblk), dim3(GB_BLOCK), lds, s, p, g, im.counters, b.inst_grad, b.reached); break;
