@@ -96,7 +96,7 @@ int gsaj_forward_preprocess(int P, int D, int M, int W, int H, const float *mean
                             void *stream) {
   return gsaj_forward_preprocess_cap(P, D, M, W, H, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
                                      cov3D_precomp, viewmatrix, projmatrix, campos, tanfovx, tanfovy, prefiltered, radii,
-                                     n_touched, geom_ws, image_ws, 0, stream);
+                                     n_touched, geom_ws, image_ws, 0, 0, stream);
 }
 
 int gsaj_forward_preprocess_cap(int P, int D, int M, int W, int H, const float *means3D, const float *shs,
@@ -104,7 +104,7 @@ int gsaj_forward_preprocess_cap(int P, int D, int M, int W, int H, const float *
                                 float scale_modifier, const float *rotations, const float *cov3D_precomp,
                                 const float *viewmatrix, const float *projmatrix, const float *campos, float tanfovx,
                                 float tanfovy, int prefiltered, int *radii, int *n_touched, void *geom_ws, void *image_ws,
-                                int capacity, void *stream) {
+                                int capacity, int tile_list_capacity, void *stream) {
   if (P <= 0 || W <= 0 || H <= 0 || !means3D || !opacities || !viewmatrix || !projmatrix || !geom_ws || !image_ws ||
       !n_touched) {
     gsaj_set_error("gsaj_forward_preprocess: invalid argument (P=%d W=%d H=%d)", P, W, H);
@@ -136,6 +136,7 @@ int gsaj_forward_preprocess_cap(int P, int D, int M, int W, int H, const float *
   p.prefiltered = prefiltered;
   p.grid_x = (W + TILE - 1) / TILE; p.grid_y = (H + TILE - 1) / TILE;
   p.capacity = capacity;
+  p.sort_cap = (tile_list_capacity > 0 && tile_list_capacity < SORT_CAP) ? tile_list_capacity : SORT_CAP;
   ImageWS im;
   image_carve(align_base(image_ws), W, H, &im);
   return launch_preprocess(p, radii ? radii : g.internal_radii, n_touched, g, im, (hipStream_t)stream);
@@ -211,7 +212,7 @@ int gsaj_forward_render(int P, int R, int max_tile_list, int W, int H, const flo
   int rc;
   if (max_tile_list >= 0 && max_tile_list <= SORT_CAP) {
     // fast path: per-tile lists sorted in LDS
-    if ((rc = launch_tile_binning(P, R, gx, gy, rad, features, g, b, im, s)) != GSAJ_OK) return rc;
+    if ((rc = launch_tile_binning(P, R, max_tile_list, gx, gy, rad, features, g, b, im, s)) != GSAJ_OK) return rc;
   } else {
     // a tile list exceeds the LDS sort capacity (or the caller forces it with max_tile_list < 0):
     // global radix sort of (tile << 32 | depth) keys, as the reference does
@@ -248,7 +249,7 @@ int gsaj_rasterize_forward_async(int P, int D, int M, const float *bg, int W, in
                                  const float *viewmatrix, const float *projmatrix, const float *campos, float tanfovx,
                                  float tanfovy, int prefiltered, float *out_color, float *out_depth, float *out_opacity,
                                  int *radii, int *n_touched, void *geom_ws, void *binning_ws, size_t binning_ws_bytes,
-                                 int capacity, void *image_ws, void *stream) {
+                                 int capacity, int tile_list_capacity, void *image_ws, void *stream) {
   if (capacity <= 0 || !binning_ws || !bg || !out_color || !out_depth || !out_opacity || !n_touched) {
     gsaj_set_error("gsaj_rasterize_forward_async: invalid argument");
     return GSAJ_ERR_INVALID_ARGUMENT;
@@ -259,7 +260,7 @@ int gsaj_rasterize_forward_async(int P, int D, int M, const float *bg, int W, in
   }
   int rc = gsaj_forward_preprocess_cap(P, D, M, W, H, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
                                        rotations, cov3D_precomp, viewmatrix, projmatrix, campos, tanfovx, tanfovy,
-                                       prefiltered, radii, n_touched, geom_ws, image_ws, capacity, stream);
+                                       prefiltered, radii, n_touched, geom_ws, image_ws, capacity, tile_list_capacity, stream);
   if (rc != GSAJ_OK) return rc;
   // No host round trip: grids do not depend on R, the arena is carved for `capacity` instances, and
   // k_scan aborts the frame on the device if R or a tile list does not fit (gsaj_forward_num_rendered
@@ -274,7 +275,8 @@ int gsaj_rasterize_forward_async(int P, int D, int M, const float *bg, int W, in
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
   const int *rad = radii ? radii : g.internal_radii;
   const float *features = colors_precomp ? colors_precomp : g.rgb;
-  if ((rc = launch_tile_binning(P, capacity, gx, gy, rad, features, g, b, im, s)) != GSAJ_OK) return rc;
+  const int sort_cap = (tile_list_capacity > 0 && tile_list_capacity < SORT_CAP) ? tile_list_capacity : SORT_CAP;
+  if ((rc = launch_tile_binning(P, capacity, sort_cap, gx, gy, rad, features, g, b, im, s)) != GSAJ_OK) return rc;
   return launch_render_forward(W, H, gx, gy, bg, b, im, out_color, out_depth, out_opacity, n_touched, s);
 }
 

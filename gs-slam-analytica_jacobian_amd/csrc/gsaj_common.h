@@ -173,10 +173,11 @@ struct FwdParams {
   int prefiltered;
   int grid_x, grid_y;
   int capacity;  // > 0: async forward, binning arena holds this many instances
+  int sort_cap;  // async forward: longest tile list the caller sized the LDS sort for (0: SORT_CAP)
 };
 
 int launch_preprocess(const FwdParams &p, int *radii, int *n_touched, const GeomWS &g, const ImageWS &im, hipStream_t s);
-int launch_tile_binning(int P, int R, int grid_x, int grid_y, const int *radii, const float *features, const GeomWS &g,
+int launch_tile_binning(int P, int R, int sort_cap, int grid_x, int grid_y, const int *radii, const float *features, const GeomWS &g,
                         const BinWS &b, const ImageWS &im, hipStream_t s);
 int launch_emit_keys(int P, int grid_x, int grid_y, const int *radii, const GeomWS &g, const BinWS &b, hipStream_t s);
 int launch_sort(int R, int end_bit, const BinWS &b, hipStream_t s);

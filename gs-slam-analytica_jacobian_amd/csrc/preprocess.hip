@@ -102,7 +102,7 @@ __device__ __forceinline__ float3 sh_to_rgb(int deg, float3 pos, float3 campos, 
   return make_float3(out[0], out[1], out[2]);
 }
 
-__device__ void frame_scan(int nblk, int tiles, int capacity, uint32_t *block_sums, ImageWS im);
+__device__ void frame_scan(int nblk, int tiles, int capacity, int sort_cap, uint32_t *block_sums, ImageWS im);
 
 __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__restrict__ radii, int *__restrict__ n_touched,
                                                          GeomWS g, ImageWS im) {
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__re
   if (tid == 0)
     s_last = __hip_atomic_fetch_add(&im.counters[5], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
   __syncthreads();
-  if (s_last) frame_scan((int)gridDim.x, tiles, p.capacity, g.block_sums, im);
+  if (s_last) frame_scan((int)gridDim.x, tiles, p.capacity, p.sort_cap, g.block_sums, im);
 }
 
 // Exclusive scan of n items by ONE workgroup of PRE_BLOCK lanes: each lane sums a contiguous run, the
@@ -277,7 +277,7 @@ __device__ uint32_t tail_exclusive_scan(const uint32_t *in, uint32_t *out, int n
 // rasterizer_impl.cu:327 and a separate launch): (1) exclusive offsets of the per-workgroup Gaussian
 // totals and the grand total R; (2) exclusive offsets of the per-tile histogram; (3) the longest
 // tile list; (4) for the async forward, the device-side capacity check.
-__device__ void frame_scan(int nblk, int tiles, int capacity, uint32_t *block_sums, ImageWS im) {
+__device__ void frame_scan(int nblk, int tiles, int capacity, int sort_cap, uint32_t *block_sums, ImageWS im) {
   const uint32_t R = tail_exclusive_scan(block_sums, block_sums, nblk, nullptr);
   uint32_t m = 0;
   const uint32_t R2 = tail_exclusive_scan(im.tile_count, im.tile_offset, tiles, &m);
@@ -289,7 +289,7 @@ __device__ void frame_scan(int nblk, int tiles, int capacity, uint32_t *block_su
     if (R2 != R) err |= ERR_INTERNAL;  // cannot happen; guards the invariant sum(tile lists) == sum(tiles_touched)
     if (capacity > 0) {  // async forward: nobody on the host will look at R before the next kernels run
       if (R > (uint32_t)capacity) err |= ERR_CAPACITY;
-      if (m > SORT_CAP) err |= ERR_TILE_LIST;
+      if (m > (uint32_t)(sort_cap > 0 ? sort_cap : SORT_CAP)) err |= ERR_TILE_LIST;
       if (err) {
         im.counters[4] = 1u;  // the remaining kernels of this frame return immediately
         atomicAdd(&im.sticky[0], 1u);
@@ -369,22 +369,33 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scatter_instances(int P, int gx, 
 // One workgroup per tile: bitonic sort of the tile's (depth, id) keys in LDS, then the sorted
 // Gaussian ids, the 48-byte instance records, the emission-slot -> sorted-position map and the
 // tile's [start, end) range are written in one pass.
+GSAJ_TRACE_DEFINE(sort)
+
 __global__ __launch_bounds__(256) void k_tile_sort_records(int gx, int gy, const int *__restrict__ radii,
                                                            const float *__restrict__ features, GeomWS g, ImageWS im,
                                                            const uint64_t *__restrict__ inst_key,
                                                            uint32_t *__restrict__ point_list,
-                                                           float4 *__restrict__ records) {
-  __shared__ uint64_t keys[SORT_CAP];
+                                                           float4 *__restrict__ records, int cap) {
+  // `cap` keys of dynamic LDS: the host sizes it to the longest tile list (sync path: known exactly; async path: the
+  // caller's tile_list_capacity, checked on the device by frame_scan), so short lists do not pay for 32 KB per workgroup
+  extern __shared__ uint64_t keys[];
   if (im.counters[4]) return;  // aborted async frame
+  GSAJ_TRACE_BEGIN(sort)
+#ifdef GSAJ_BLOCK_TRACE
+  unsigned long long tr_a = wall_clock64(), tr_b = 0, tr_c = 0;
+#endif
   const int tid = threadIdx.x, tile = blockIdx.x;
   const uint32_t beg = im.tile_offset[tile * TILE_REP], end = im.tile_offset[(tile + 1) * TILE_REP];
   const int n = (int)(end - beg);
   if (tid == 0) im.ranges[tile] = n > 0 ? make_uint2(beg, end) : make_uint2(0u, 0u);
-  if (n == 0) return;
+  if (n == 0 || n > cap) return;  // (n > cap: the frame has been flagged by frame_scan / the host chose the global sort)
   int m = 2;
   while (m < n) m <<= 1;
   for (int i = tid; i < m; i += 256) keys[i] = i < n ? inst_key[beg + i] : ~0ull;
   __syncthreads();
+#ifdef GSAJ_BLOCK_TRACE
+  tr_b = wall_clock64();
+#endif
   // Bitonic network.  Comparators with stride j <= 64 pair keys inside one aligned 128-key chunk, so
   // a wave that owns whole chunks runs ALL such consecutive stages without a workgroup barrier
   // (LDS operations of one wave complete in order); only strides >= 128 need __syncthreads.
@@ -417,6 +428,9 @@ __global__ __launch_bounds__(256) void k_tile_sort_records(int gx, int gy, const
     }
     __syncthreads();
   }
+#ifdef GSAJ_BLOCK_TRACE
+  tr_c = wall_clock64();
+#endif
   const int ty = tile / gx, tx = tile - ty * gx;
   for (int i = tid; i < n; i += 256) {
     const uint64_t key = keys[i];
@@ -431,6 +445,14 @@ __global__ __launch_bounds__(256) void k_tile_sort_records(int gx, int gy, const
     records[(size_t)k * REC_F4 + 1] = bq;
     records[(size_t)k * REC_F4 + 2] = make_float4(c.x, c.y, c.z, __uint_as_float(u));
   }
+  GSAJ_TRACE_END(sort)
+#ifdef GSAJ_BLOCK_TRACE
+  if ((threadIdx.x & 63) == 0) {
+    unsigned long long *t = g_trace_sort + 4 * (blockIdx.x * 4 + (threadIdx.x >> 6));
+    t[2] = tr_b - tr_a;
+    t[3] = tr_c - tr_b;
+  }
+#endif
 }
 
 // One (tile, depth) key + Gaussian id per touched tile, written at the Gaussian's slot range.
@@ -478,8 +500,8 @@ int launch_preprocess(const FwdParams &p, int *radii, int *n_touched, const Geom
   return GSAJ_OK;
 }
 
-int launch_tile_binning(int P, int R, int grid_x, int grid_y, const int *radii, const float *features, const GeomWS &g,
-                        const BinWS &b, const ImageWS &im, hipStream_t s) {
+int launch_tile_binning(int P, int R, int sort_cap, int grid_x, int grid_y, const int *radii, const float *features,
+                        const GeomWS &g, const BinWS &b, const ImageWS &im, hipStream_t s) {
   (void)R;
   const int nblk = (P + PRE_BLOCK - 1) / PRE_BLOCK;
   {
@@ -491,8 +513,10 @@ int launch_tile_binning(int P, int R, int grid_x, int grid_y, const int *radii, 
   }
   {
     GsajProfScope ps(ST_TILE_SORT, s);
-    hipLaunchKernelGGL(k_tile_sort_records, dim3(grid_x * grid_y), dim3(256), 0, s, grid_x, grid_y, radii, features, g, im,
-                       b.keys_unsorted, b.point_list, b.records);
+    int cap = 128;
+    while (cap < sort_cap && cap < SORT_CAP) cap <<= 1;
+    hipLaunchKernelGGL(k_tile_sort_records, dim3(grid_x * grid_y), dim3(256), sizeof(uint64_t) * (size_t)cap, s, grid_x, grid_y,
+                       radii, features, g, im, b.keys_unsorted, b.point_list, b.records, cap);
   }
   GSAJ_HIP_CHECK(hipGetLastError());
   return GSAJ_OK;

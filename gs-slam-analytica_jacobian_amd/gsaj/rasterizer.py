@@ -255,6 +255,7 @@ class FrameContext:
         self.binning = torch.empty(0, **byte)
         self.R = 0
         self.capacity = 0  # > 0 once an arena has been sized: enables forward(sync=False)
+        self.tile_list_capacity = 0  # longest tile list asynchronous frames may contain (0: the maximum, 4096)
         # per-Gaussian parameter gradients live in ONE flat bucket (field-major) so that a multi-GPU
         # mapping step can all-reduce it with a single collective (gsaj.keyframe_shard); `grad_slots`
         # buckets let the collective of step i overlap the kernels of step i+1
@@ -292,7 +293,8 @@ class FrameContext:
         _lib.check(self.lib.gsaj_forward_aborted_count(self.W, self.H, self.img.data_ptr(), _stream(self.dev),
                                                        ctypes.byref(n)), "gsaj_forward_aborted_count")
         if n.value:
-            raise _lib.GsajError("%d asynchronous forward(s) were aborted on the device (binning arena too small)" % n.value)
+            raise _lib.GsajError("%d asynchronous forward(s) were aborted on the device (binning arena too small or a tile list "
+                                 "longer than tile_list_capacity=%d); run forward(sync=True) to re-size" % (n.value, self.tile_list_capacity))
         return R.value, mt.value
 
     def forward(self, bg, means3D, opacities, viewmatrix, projmatrix, campos, tanfovx, tanfovy, sh_degree=0, shs=None,
@@ -308,7 +310,7 @@ class FrameContext:
                 _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tanfovx), float(tanfovy), 0,
                 self.color.data_ptr(), self.depth.data_ptr(), self.opacity.data_ptr(), self.radii.data_ptr(),
                 self.n_touched.data_ptr(), self.geom.data_ptr(), self.binning.data_ptr(), self.binning.numel(),
-                self.capacity, self.img.data_ptr(), st), "gsaj_rasterize_forward_async")
+                self.capacity, self.tile_list_capacity, self.img.data_ptr(), st), "gsaj_rasterize_forward_async")
             self.R = self.capacity  # what the backward must be given (arena carving)
             return self.R
         _lib.check(lib.gsaj_forward_preprocess(
@@ -320,6 +322,9 @@ class FrameContext:
         _lib.check(lib.gsaj_forward_num_rendered(self.W, self.H, self.img.data_ptr(), st, ctypes.byref(R), ctypes.byref(mt)),
                    "gsaj_forward_num_rendered")
         self.R, self.max_tile_list = R.value, mt.value
+        # asynchronous frames get an LDS sort sized for twice the longest tile list seen so far (a longer list aborts
+        # the frame on the device, exactly like an arena overflow: status() raises, forward(sync=True) recovers)
+        self.tile_list_capacity = min(4096, max(self.tile_list_capacity, 2 * self.max_tile_list, 256))
         self._ensure_binning(self.R)
         self.true_R = self.R
         _lib.check(lib.gsaj_forward_render(

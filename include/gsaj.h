@@ -107,7 +107,9 @@ int gsaj_rasterize_forward(int P, int D, int M, const float *bg, int W, int H,
  * gsaj_forward_num_rendered -- which may be called at any later time -- returns
  * GSAJ_ERR_WORKSPACE_TOO_SMALL together with the R to size the arena for; the caller then repeats
  * the frame (with a larger arena, or through the synchronising entry points, which also have the
- * global-sort fallback). */
+ * global-sort fallback).  tile_list_capacity (0 = the maximum, 4096): the longest tile list the frame may
+ * contain; the per-tile LDS sort is given exactly that much shared memory, so scenes with short lists keep
+ * more workgroups resident.  A frame with a longer list is aborted like one that overflows the arena. */
 int gsaj_rasterize_forward_async(int P, int D, int M, const float *bg, int W, int H,
                                  const float *means3D, const float *shs, const float *colors_precomp,
                                  const float *opacities, const float *scales, float scale_modifier,
@@ -115,7 +117,7 @@ int gsaj_rasterize_forward_async(int P, int D, int M, const float *bg, int W, in
                                  const float *viewmatrix, const float *projmatrix, const float *campos,
                                  float tanfovx, float tanfovy, int prefiltered,
                                  float *out_color, float *out_depth, float *out_opacity, int *radii, int *n_touched,
-                                 void *geom_ws, void *binning_ws, size_t binning_ws_bytes, int capacity,
+                                 void *geom_ws, void *binning_ws, size_t binning_ws_bytes, int capacity, int tile_list_capacity,
                                  void *image_ws, void *stream);
 /* Blocking: number of async forwards aborted on the device since the image workspace was zeroed by
  * the caller (the caller zero-fills the image workspace once, when it allocates it). */
@@ -127,7 +129,7 @@ int gsaj_forward_preprocess_cap(int P, int D, int M, int W, int H,
                                 const float *rotations, const float *cov3D_precomp,
                                 const float *viewmatrix, const float *projmatrix, const float *campos,
                                 float tanfovx, float tanfovy, int prefiltered, int *radii, int *n_touched,
-                                void *geom_ws, void *image_ws, int capacity, void *stream);
+                                void *geom_ws, void *image_ws, int capacity, int tile_list_capacity, void *stream);
 
 /* ---- backward ------------------------------------------------------------------------ */
 /* dL_dpix [3,H,W], dL_dpix_depth [1,H,W] -> dL_dmean2D [P,3] (NDC-scaled, z unused),

@@ -302,3 +302,14 @@ def test_async_forward_matches_sync_and_reports_overflow(torch_cuda):
     ctx.forward(**args, sync=False)
     with pytest.raises(_lib.GsajError, match="too small|aborted"):
         ctx.status()
+    # same for a tile list longer than the LDS sort was sized for
+    ctx2 = FrameContext(P, cam["W"], cam["H"], M, dev)
+    ctx2.forward(**args, sync=True)
+    longest = ctx2.status()[1]
+    assert ctx2.tile_list_capacity >= 2 * longest or ctx2.tile_list_capacity == 4096
+    ctx2.forward(**args, sync=False)
+    assert torch.equal(ctx2.color, ref[0])
+    ctx2.tile_list_capacity = max(1, longest // 2)
+    ctx2.forward(**args, sync=False)
+    with pytest.raises(_lib.GsajError, match="tile list|aborted"):
+        ctx2.status()

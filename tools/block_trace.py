@@ -38,7 +38,9 @@ def main():
     torch.cuda.synchronize()
     nw = ((W + 15) // 16) * ((H + 15) // 16) * 4
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    for name in ("fwd", "bwd"):
+    for name in ("fwd", "bwd", "sort"):
+        if not hasattr(lib, "gsaj_trace_read_" + name):
+            continue
         fn = getattr(lib, "gsaj_trace_read_" + name)
         fn.argtypes, fn.restype = [ctypes.c_void_p, ctypes.c_int], ctypes.c_int
         buf = np.zeros((nw, 4), np.uint64)
@@ -51,6 +53,10 @@ def main():
               "p5/p50/p95 life %.1f %.1f %.1f" % tuple(np.percentile(life, [5, 50, 95])),
               "start p50/p95/max us %.1f %.1f %.1f" % tuple(np.percentile((s - t0) * 0.01, [50, 95, 100])),
               "end p5/p50/p95 us %.1f %.1f %.1f" % tuple(np.percentile((e - t0) * 0.01, [5, 50, 95])))
+        if name == "sort":
+            print("   sort phases per wave (us): load keys %.1f  sort %.1f  ids+records %.1f" % (
+                buf[:, 2].astype(np.int64).mean() * 0.01, buf[:, 3].astype(np.int64).mean() * 0.01,
+                (life - (buf[:, 2] + buf[:, 3]).astype(np.int64) * 0.01).mean()))
 
 
 if __name__ == "__main__":
