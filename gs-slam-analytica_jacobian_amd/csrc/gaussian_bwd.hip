@@ -98,6 +98,8 @@ __device__ __forceinline__ float3 sh_backward(int deg, int M, float3 pos, float3
 }
 
 // SHW = 3*M as a compile-time constant (0: runtime) -- the staging loops divide by it per element
+GSAJ_TRACE_DEFINE(gbwd)
+
 template <int SHW>
 __global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g, uint32_t *__restrict__ counters,
                                                            const float4 *__restrict__ inst_grad,
@@ -105,6 +107,13 @@ __global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g
   extern __shared__ float sh_lds[];  // [GB_BLOCK][3M+1]: SH coefficients in, overwritten in place by dL/dSH (padded rows)
   __shared__ uint32_t s_ticket;
   if (counters[4]) return;  // aborted async frame
+  GSAJ_TRACE_BEGIN(gbwd)
+#ifdef GSAJ_BLOCK_TRACE
+  unsigned long long tr_[5] = {0, 0, 0, 0, 0}, tr_t = wall_clock64();
+#define TRM(i) { const unsigned long long n_ = wall_clock64(); tr_[i] += n_ - tr_t; tr_t = n_; }
+#else
+#define TRM(i)
+#endif
   const int tid = threadIdx.x;
   const int idx = blockIdx.x * GB_BLOCK + tid;
   const int shw = SHW > 0 ? SHW : 3 * p.M, shs_stride = shw + 1;
@@ -119,6 +128,25 @@ __global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g
   const uint32_t cnt = idx < p.P ? g.tiles_touched[ii] : 0u;
   const uint32_t endi = idx < p.P ? g.point_offsets[ii] : 0u;
   const uint32_t first = endi - cnt;
+  // The wave's rows [F, E) of inst_grad are gathered in trips of 256; the first trip's flag and row loads (two dependent
+  // round trips) are issued NOW, so that they overlap the input loads and the SH staging below.
+  const uint32_t F = (uint32_t)__shfl((int)first, 0);
+  uint32_t E = endi;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) E = max(E, (uint32_t)__shfl_xor((int)E, o));
+  float4 a[4][3];
+  auto load_trip = [&](uint32_t lo, uint32_t hi) {
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      const uint32_t r = lo + (uint32_t)(w * GB_BLOCK + tid);
+      a[w][0] = a[w][1] = a[w][2] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < hi && reached[r]) {  // rows the reverse compositor never wrote are zero by definition
+        const float4 *src = inst_grad + (size_t)r * REC_F4;
+        a[w][0] = src[0]; a[w][1] = src[1]; a[w][2] = src[2];
+      }
+    }
+  };
+  load_trip(F, min(F + 256u, E));
   const float3 mean = make_float3(p.means3D[3 * ii], p.means3D[3 * ii + 1], p.means3D[3 * ii + 2]);
   float c6[6];
 #pragma unroll
@@ -153,6 +181,7 @@ __global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g
     }
     __syncthreads();
   }
+  TRM(0)
   float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   // ---- 1. gather the instance partials.  Tiles-per-Gaussian is heavy-tailed (mean ~8, max > 100), so a
   //         per-lane loop over global memory makes the whole wave wait for its largest Gaussian.
@@ -162,22 +191,9 @@ __global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g
   float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0;
   {
     __shared__ float4 rows[256 * REC_F4];
-    const uint32_t F = (uint32_t)__shfl((int)first, 0);
-    uint32_t E = endi;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) E = max(E, (uint32_t)__shfl_xor((int)E, o));
     for (uint32_t lo = F; lo < E; lo += 256) {
       const uint32_t hi = min(lo + 256u, E);
-      float4 a[4][3];
-#pragma unroll
-      for (int w = 0; w < 4; w++) {
-        const uint32_t r = lo + (uint32_t)(w * GB_BLOCK + tid);
-        a[w][0] = a[w][1] = a[w][2] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < hi && reached[r]) {  // rows the reverse compositor never wrote are zero by definition
-          const float4 *src = inst_grad + (size_t)r * REC_F4;
-          a[w][0] = src[0]; a[w][1] = src[1]; a[w][2] = src[2];
-        }
-      }
+      if (lo != F) load_trip(lo, hi);
 #pragma unroll
       for (int w = 0; w < 4; w++) {
         rows[(w * GB_BLOCK + tid) * REC_F4 + 0] = a[w][0];
@@ -195,6 +211,7 @@ __global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g
       __syncthreads();
     }
   }
+  TRM(1)
   // every output of this Gaussian stays in registers until the dL/dtau hand-off below has been made:
   // the hand-off drains this wave's outstanding stores (s_waitcnt vmcnt(0)), so the bulk stores come last
   float o_m2x = 0.f, o_m2y = 0.f, o_ca = 0.f, o_cb = 0.f, o_cc = 0.f, o_op = 0.f, o_dz = 0.f;
@@ -352,6 +369,7 @@ __global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g
       o_rot = dq;
     }
   }
+  TRM(2)
   // ---- 7. wave partial of dL/dtau (fixed butterfly) ----
 #pragma unroll
   for (int k = 0; k < 6; k++) {
@@ -377,10 +395,21 @@ __global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g
   if (s_ticket == gridDim.x - 1) {
   const int nblk = (int)gridDim.x;
   double acc6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  for (int i = tid; i < nblk; i += GB_BLOCK) {  // rows are independent loads: all in flight at once
+  for (int i0 = tid; i0 < nblk; i0 += 4 * GB_BLOCK) {  // 24 independent loads in flight per trip, summed in row order
+    float v[4][6];
 #pragma unroll
-    for (int k = 0; k < 6; k++)
-      acc6[k] += (double)__hip_atomic_load(&g.tau_partials[(size_t)i * 8 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int u = 0; u < 4; u++) {
+      const int i = i0 + u * GB_BLOCK, ic = min(i, nblk - 1);  // unconditional loads (a guarded atomic load becomes a
+#pragma unroll                                                       // branch + s_waitcnt vmcnt(0) each), masked afterwards
+      for (int k = 0; k < 6; k++) {
+        const float t = __hip_atomic_load(&g.tau_partials[(size_t)ic * 8 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v[u][k] = i < nblk ? t : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+      for (int k = 0; k < 6; k++) acc6[k] += (double)v[u][k];
   }
 #pragma unroll
   for (int k = 0; k < 6; k++) {
@@ -392,6 +421,7 @@ __global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g
   if (tid == 0) counters[3] = 0u;  // ready for the next backward over this workspace
   }
   }
+  TRM(3)
   // ---- 9. outputs: one row per Gaussian, zeros for culled ones (the reference's binding memsets first) ----
   if (idx < p.P) {
     const size_t i = (size_t)idx;
@@ -425,6 +455,15 @@ __global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g
       p.dL_dsh[base + e] = sh_io[gi * shs_stride + k];
     }
   }
+  TRM(4)
+  GSAJ_TRACE_END(gbwd)
+#ifdef GSAJ_BLOCK_TRACE
+  if (tid == 0 && blockIdx.x < GSAJ_TRACE_MAX) {
+    unsigned long long *t = g_trace_gbwd + 4 * blockIdx.x;
+    t[2] = (tr_[0] << 42) | (tr_[1] << 21) | tr_[2];
+    t[3] = (tr_[3] << 21) | tr_[4];
+  }
+#endif
 }
 
 int launch_gaussian_backward(const BwdParams &p, const GeomWS &g, const BinWS &b, const ImageWS &im, hipStream_t s) {

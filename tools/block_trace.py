@@ -38,21 +38,28 @@ def main():
     torch.cuda.synchronize()
     nw = ((W + 15) // 16) * ((H + 15) // 16) * 4
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    for name in ("fwd", "bwd", "sort"):
+    for name in ("fwd", "bwd", "sort", "gbwd"):
         if not hasattr(lib, "gsaj_trace_read_" + name):
             continue
         fn = getattr(lib, "gsaj_trace_read_" + name)
         fn.argtypes, fn.restype = [ctypes.c_void_p, ctypes.c_int], ctypes.c_int
-        buf = np.zeros((nw, 4), np.uint64)
-        assert fn(buf.ctypes.data, nw) == 0
+        n_rec = (P + 63) // 64 if name == "gbwd" else nw
+        buf = np.zeros((n_rec, 4), np.uint64)
+        assert fn(buf.ctypes.data, n_rec) == 0
         np.save(os.path.join(ROOT, "gpurun_out", "block_trace_%s.npy" % name), buf)
         s, e = buf[:, 0].astype(np.int64), buf[:, 1].astype(np.int64)
         t0 = s.min()
         life = (e - s) * 0.01
-        print(name, "waves", nw, "span us %.1f" % ((e.max() - t0) * 0.01), "mean life us %.1f" % life.mean(),
+        print(name, "waves", len(buf), "span us %.1f" % ((e.max() - t0) * 0.01), "mean life us %.1f" % life.mean(),
               "p5/p50/p95 life %.1f %.1f %.1f" % tuple(np.percentile(life, [5, 50, 95])),
               "start p50/p95/max us %.1f %.1f %.1f" % tuple(np.percentile((s - t0) * 0.01, [50, 95, 100])),
               "end p5/p50/p95 us %.1f %.1f %.1f" % tuple(np.percentile((e - t0) * 0.01, [5, 50, 95])))
+        if name == "gbwd":
+            m21 = np.uint64(0x1fffff)
+            a, b = buf[:, 2], buf[:, 3]
+            ph = [(a >> np.uint64(42)), (a >> np.uint64(21)) & m21, a & m21, (b >> np.uint64(21)) & m21, b & m21]
+            print("   gbwd phases per wave (us): inputs+SH stage %.1f  gather rows %.1f  math+SH %.1f  tau hand-off %.1f  stores %.1f" % tuple(
+                x.astype(np.int64).mean() * 0.01 for x in ph))
         if name == "sort":
             print("   sort phases per wave (us): load keys %.1f  sort %.1f  ids+records %.1f" % (
                 buf[:, 2].astype(np.int64).mean() * 0.01, buf[:, 3].astype(np.int64).mean() * 0.01,
