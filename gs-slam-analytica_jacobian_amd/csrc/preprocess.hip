@@ -104,10 +104,19 @@ __device__ __forceinline__ float3 sh_to_rgb(int deg, float3 pos, float3 campos, 
 
 __device__ void frame_scan(int nblk, int tiles, int capacity, int sort_cap, uint32_t *block_sums, ImageWS im);
 
+GSAJ_TRACE_DEFINE(pre)
+
 __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__restrict__ radii, int *__restrict__ n_touched,
                                                          GeomWS g, ImageWS im) {
   __shared__ uint32_t scan[PRE_BLOCK];
   extern __shared__ uint32_t hist[];  // [tiles] workgroup-local tile histogram (when tiles <= LDS_TILES_MAX)
+  GSAJ_TRACE_BEGIN(pre)
+#ifdef GSAJ_BLOCK_TRACE
+  unsigned long long trp_[4] = {0, 0, 0, 0}, trp_t = wall_clock64();
+#define TRP(i) { const unsigned long long n_ = wall_clock64(); trp_[i] += n_ - trp_t; trp_t = n_; }
+#else
+#define TRP(i)
+#endif
   const int tid = threadIdx.x;
   const int idx = blockIdx.x * PRE_BLOCK + tid;
   const int tiles = p.grid_x * p.grid_y;
@@ -126,7 +135,26 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__re
     float3 rgb = make_float3(0.f, 0.f, 0.f);
     uint8_t cl[3] = {0, 0, 0};
     float c6s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // every input of this Gaussian is requested up front (one memory round trip instead of three dependent ones:
+    // the kernel is latency-bound, < 1 workgroup per CU); culled Gaussians simply do not use theirs
     const float3 p_orig = ld3(p.means3D, idx);
+    float3 sc_in = make_float3(0.f, 0.f, 0.f);
+    float4 q_in = make_float4(1.f, 0.f, 0.f, 0.f);
+    if (!p.cov3D_precomp) {
+      sc_in = ld3(p.scales, idx);
+      q_in = reinterpret_cast<const float4 *>(p.rotations)[idx];
+    }
+    const float opac_in = p.opacities[idx];
+    const bool sh_regs = !p.colors_precomp && p.M == 16;  // degree-3 storage: 48 floats = 12 x 16-byte loads
+    float shv[48];
+    if (sh_regs) {
+      const float4 *s4 = reinterpret_cast<const float4 *>(p.shs + (size_t)idx * 48);
+#pragma unroll
+      for (int k = 0; k < 12; k++) {
+        const float4 t = s4[k];
+        shv[4 * k] = t.x; shv[4 * k + 1] = t.y; shv[4 * k + 2] = t.z; shv[4 * k + 3] = t.w;
+      }
+    }
     const float3 p_view = xform4x3(p.viewmatrix, p_orig);
     if (p_view.z <= 0.2f) {
       if (p.prefiltered) atomicOr(&im.counters[1], ERR_PREFILTERED);  // the reference traps here (auxiliary.h:156-160)
@@ -138,9 +166,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__re
       if (p.cov3D_precomp) {
         c6 = p.cov3D_precomp + 6 * (size_t)idx;
       } else {
-        const float3 sc = ld3(p.scales, idx);
-        const float4 q = reinterpret_cast<const float4 *>(p.rotations)[idx];
-        cov3d_from_scale_rot(sc, p.scale_modifier, q, c6s);
+        cov3d_from_scale_rot(sc_in, p.scale_modifier, q_in, c6s);
         c6 = c6s;
       }
       const float3 cov = cov2d_forward(p_orig, p.focal_x, p.focal_y, p.tanfovx, p.tanfovy, c6, p.viewmatrix);
@@ -159,13 +185,14 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__re
         if (area != 0) {
           if (!p.colors_precomp) {
             const float3 cam = make_float3(p.campos[0], p.campos[1], p.campos[2]);
-            rgb = sh_to_rgb(p.D, p_orig, cam, p.shs + (size_t)idx * p.M * 3, cl);
+            if (sh_regs) rgb = sh_to_rgb(p.D, p_orig, cam, shv, cl);
+            else rgb = sh_to_rgb(p.D, p_orig, cam, p.shs + (size_t)idx * p.M * 3, cl);
           }
           rect_pack = (uint32_t)x0 | ((uint32_t)y0 << 10) | ((uint32_t)(x1 - x0) << 20);
           depth = p_view.z;
           my_radius_i = (int)my_radius;
           xy = pim;
-          con_o = make_float4(conic.x, conic.y, conic.z, p.opacities[idx]);
+          con_o = make_float4(conic.x, conic.y, conic.z, opac_in);
           touched = (uint32_t)area;
           // per-tile instance histogram: LDS atomics here, one coalesced global flush per workgroup
           // (a scattered global atomic wave-instruction costs ~17x a contiguous one)
@@ -196,6 +223,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__re
     g.splat[3 * (size_t)idx + 1] = con_o;
     g.splat[3 * (size_t)idx + 2] = make_float4(rgb.x, rgb.y, rgb.z, 0.f);
   }
+  TRP(0)
   // block-local inclusive scan of tiles_touched (Hillis-Steele over 256 lanes)
   scan[tid] = touched;
   __syncthreads();
@@ -218,13 +246,24 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__re
   // hand-off (counter form): every wave drains its histogram atomics / sc1 store, the workgroup
   // meets at a barrier, one lane draws a relaxed agent-scope ticket; the last arriver reads the
   // other workgroups' data with sc1 loads only.
+  TRP(1)
   __shared__ uint32_t s_last;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0)
     s_last = __hip_atomic_fetch_add(&im.counters[5], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
   __syncthreads();
+  TRP(2)
   if (s_last) frame_scan((int)gridDim.x, tiles, p.capacity, p.sort_cap, g.block_sums, im);
+  TRP(3)
+  GSAJ_TRACE_END(pre)
+#ifdef GSAJ_BLOCK_TRACE
+  if ((threadIdx.x & 63) == 0) {
+    unsigned long long *t = g_trace_pre + 4 * (blockIdx.x * (PRE_BLOCK / 64) + (threadIdx.x >> 6));
+    t[2] = (trp_[0] << 32) | trp_[1];
+    t[3] = (trp_[2] << 32) | trp_[3];
+  }
+#endif
 }
 
 // Exclusive scan of n items by ONE workgroup of PRE_BLOCK lanes: each lane sums a contiguous run, the
