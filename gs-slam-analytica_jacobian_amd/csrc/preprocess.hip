@@ -364,10 +364,11 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scatter_instances(int P, int gx, 
     g.point_offsets[idx] = incl;
     reinterpret_cast<float *>(g.splat)[12 * (size_t)idx + 3] = __uint_as_float(incl - g.tiles_touched[idx]);
     r = radii[idx];
+    const float2 xy = g.means2D[idx];  // requested together with the radius, not after it (latency-bound kernel)
+    const float dep = g.depths[idx];
     if (r > 0) {
-      const float2 xy = g.means2D[idx];
       tile_rect(xy.x, xy.y, r, gx, gy, x0, y0, x1, y1);
-      key = ((uint64_t)__float_as_uint(g.depths[idx]) << 32) | (uint32_t)idx;
+      key = ((uint64_t)__float_as_uint(dep) << 32) | (uint32_t)idx;
     }
   }
   if (!use_lds) {
@@ -384,17 +385,18 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scatter_instances(int P, int gx, 
   // reserve this workgroup's slot range in every tile it touches: returning atomics, issued eight at
   // a time so their round trips overlap (one s_waitcnt per batch instead of one per tile)
   for (int t0 = 0; t0 < tiles; t0 += 8 * PRE_BLOCK) {
-    uint32_t c[8], base[8];
+    uint32_t c[8], base[8], off[8];
 #pragma unroll
     for (int b = 0; b < 8; b++) {
       const int t = t0 + b * PRE_BLOCK + tid;
       c[b] = t < tiles ? cnt[t] : 0u;
+      off[b] = t < tiles ? im.tile_offset[t] : 0u;  // in flight together with the atomics
       base[b] = c[b] ? atomicAdd(&im.tile_cursor[t], c[b]) : 0u;
     }
 #pragma unroll
     for (int b = 0; b < 8; b++) {
       const int t = t0 + b * PRE_BLOCK + tid;
-      if (c[b]) cnt[t] = im.tile_offset[t] + base[b];
+      if (c[b]) cnt[t] = off[b] + base[b];
     }
   }
   __syncthreads();
