@@ -12,6 +12,7 @@
 // :120-154 (computeCov3D), :22-73 (computeColorFromSH), auxiliary.h:139-164 (in_frustum),
 // rasterizer_impl.cu:70-111 (duplicateWithKeys), :54-66 (checkFrustum).
 #include "gsaj_common.h"
+#include "wave_reduce.h"
 
 __constant__ float kSH_C0 = 0.28209479177387814f;
 __constant__ float kSH_C1 = 0.4886025119029199f;
@@ -407,6 +408,58 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scatter_instances(int P, int gx, 
     }
 }
 
+// ---- register exchange for the wave-local stages of the tile sort -------------------------------
+// value of lane (l ^ J) for J = 32, 16 (v_permlane*_swap of a register with itself) and 8, 4, 2, 1 (DPP)
+template <int J>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t x, int lane) {
+  if (J == 32) {
+    const gsaj_u32x2 r = __builtin_amdgcn_permlane32_swap(x, x, false, false);  // r[0] = [lo | lo], r[1] = [hi | hi]
+    return lane < 32 ? r[1] : r[0];
+  } else if (J == 16) {
+    const gsaj_u32x2 r = __builtin_amdgcn_permlane16_swap(x, x, false, false);  // r[0] = rows [0,0,2,2], r[1] = rows [1,1,3,3]
+    return (lane & 16) ? r[0] : r[1];
+  } else if (J == 8) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xF, 0xF, false);  // row_ror:8
+  } else if (J == 4) {
+    int t = __builtin_amdgcn_update_dpp(0, (int)x, 0x104, 0xF, 0x5, false);          // row_shl:4 -> banks 0, 2 (lane <- lane + 4)
+    t = __builtin_amdgcn_update_dpp(t, (int)x, 0x114, 0xF, 0xA, false);              // row_shr:4 -> banks 1, 3 (lane <- lane - 4)
+    return (uint32_t)t;
+  } else if (J == 2) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+  } else {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+  }
+}
+// one bitonic stage of stride J < 64 on the two keys a lane holds (indices base + lane and base + 64 + lane)
+template <int J>
+__device__ __forceinline__ void sort_stage(uint64_t &A, uint64_t &B, int lane, bool ascA, bool ascB) {
+  const uint64_t PA = ((uint64_t)lane_xor<J>((uint32_t)(A >> 32), lane) << 32) | lane_xor<J>((uint32_t)A, lane);
+  const uint64_t PB = ((uint64_t)lane_xor<J>((uint32_t)(B >> 32), lane) << 32) | lane_xor<J>((uint32_t)B, lane);
+  const bool lower = (lane & J) == 0;  // this lane holds the lower-indexed key of the pair
+  A = ((A < PA) == (lower == ascA)) ? A : PA;  // lower & ascending (or upper & descending) keeps the smaller key
+  B = ((B < PB) == (lower == ascB)) ? B : PB;
+}
+
+// strides J, J/2, ..., 1 of one bitonic merge (J = 64: the in-lane comparator between a lane's two keys first)
+template <int J>
+__device__ __forceinline__ void merge_strides(uint64_t &A, uint64_t &B, int lane, bool ascA, bool ascB) {
+  if constexpr (J == 64) {
+    const uint64_t lo = A < B ? A : B, hi = A < B ? B : A;
+    A = ascA ? lo : hi;  // (stride 64 belongs to merges of size >= 128: ascA == ascB)
+    B = ascA ? hi : lo;
+  } else {
+    sort_stage<J>(A, B, lane, ascA, ascB);
+  }
+  if constexpr (J > 1) merge_strides<J / 2>(A, B, lane, ascA, ascB);
+}
+// the merges of size K, 2K, ..., 128 (all inside the chunk), stopping at the padded list length m
+template <int K>
+__device__ __forceinline__ void local_merges(uint64_t &A, uint64_t &B, int lane, int ia, int ib, int m) {
+  if (K > m) return;
+  merge_strides<K / 2>(A, B, lane, (ia & K) == 0, (ib & K) == 0);
+  if constexpr (K < 128) local_merges<2 * K>(A, B, lane, ia, ib, m);
+}
+
 // One workgroup per tile: bitonic sort of the tile's (depth, id) keys in LDS, then the sorted
 // Gaussian ids, the 48-byte instance records, the emission-slot -> sorted-position map and the
 // tile's [start, end) range are written in one pass.
@@ -437,13 +490,22 @@ __global__ __launch_bounds__(256) void k_tile_sort_records(int gx, int gy, const
 #ifdef GSAJ_BLOCK_TRACE
   tr_b = wall_clock64();
 #endif
-  // Bitonic network.  Comparators with stride j <= 64 pair keys inside one aligned 128-key chunk, so
-  // a wave that owns whole chunks runs ALL such consecutive stages without a workgroup barrier
-  // (LDS operations of one wave complete in order); only strides >= 128 need __syncthreads.
+  // Bitonic network.  Comparators with stride <= 64 pair keys inside one aligned 128-key chunk, and a wave holds a
+  // chunk in REGISTERS (lane l: keys l and l + 64): stride 64 is in-lane, strides 32 / 16 use v_permlane32_swap /
+  // v_permlane16_swap, strides 8..1 DPP -- an LDS round trip per stage was the latency of this kernel.  So the
+  // first 28 stages (k = 2..128: every chunk sorted on its own) never touch LDS, and for k >= 256 only the
+  // strides >= 128 do (with workgroup barriers), followed by the seven chunk-local stages in registers again.
   const int lane = tid & 63, wave = tid >> 6;
-  for (int k = 2; k <= m; k <<= 1) {
-    int j = k >> 1;
-    for (; j >= 128; j >>= 1) {
+  for (int chunk = wave; chunk * 128 < m; chunk += 4) {
+    const int ia = chunk * 128 + lane, ib = ia + 64;
+    uint64_t A = ia < m ? keys[ia] : ~0ull, B = ib < m ? keys[ib] : ~0ull;
+    local_merges<2>(A, B, lane, ia, ib, m);
+    if (ia < m) keys[ia] = A;
+    if (ib < m) keys[ib] = B;
+  }
+  __syncthreads();
+  for (int k = 256; k <= m; k <<= 1) {
+    for (int j = k >> 1; j >= 128; j >>= 1) {
       for (int i = tid; i < (m >> 1); i += 256) {
         const int l = ((i & ~(j - 1)) << 1) | (i & (j - 1)), r = l + j;
         const uint64_t a = keys[l], b = keys[r];
@@ -454,18 +516,13 @@ __global__ __launch_bounds__(256) void k_tile_sort_records(int gx, int gy, const
       }
       __syncthreads();
     }
-    for (int chunk = wave; chunk * 128 < m; chunk += 4) {  // 64 comparators per 128-key chunk
-      for (int jj = j; jj > 0; jj >>= 1) {
-        const int i = chunk * 64 + lane;
-        if (i < (m >> 1)) {
-          const int l = ((i & ~(jj - 1)) << 1) | (i & (jj - 1)), r = l + jj;
-          const uint64_t a = keys[l], b = keys[r];
-          if ((a > b) == ((l & k) == 0)) {
-            keys[l] = b;
-            keys[r] = a;
-          }
-        }
-      }
+    for (int chunk = wave; chunk * 128 < m; chunk += 4) {
+      const int ia = chunk * 128 + lane, ib = ia + 64;
+      uint64_t A = keys[ia], B = keys[ib];
+      const bool asc = (ia & k) == 0;  // k >= 256: one direction for the whole chunk
+      merge_strides<64>(A, B, lane, asc, asc);
+      keys[ia] = A;
+      keys[ib] = B;
     }
     __syncthreads();
   }
