@@ -345,10 +345,19 @@ __device__ void frame_scan(int nblk, int tiles, int capacity, int sort_cap, uint
 // slots with LDS atomics.  Slot order inside a tile is arbitrary; the tile sort orders by
 // (depth, id), a total order, so the final lists are deterministic.
 // Also turns point_offsets into the global inclusive scan (emission slots for the backward).
+GSAJ_TRACE_DEFINE(scat)
+
 __global__ __launch_bounds__(PRE_BLOCK) void k_scatter_instances(int P, int gx, int gy, const int *__restrict__ radii,
                                                                  GeomWS g, ImageWS im, uint64_t *__restrict__ inst_key) {
   extern __shared__ uint32_t lds[];  // [2*tiles]: count -> reserved base, fill cursor
   if (im.counters[4]) return;  // aborted async frame
+  GSAJ_TRACE_BEGIN(scat)
+#ifdef GSAJ_BLOCK_TRACE
+  unsigned long long trs_[4] = {0, 0, 0, 0}, trs_t = wall_clock64();
+#define TRS(i) { const unsigned long long n_ = wall_clock64(); trs_[i] += n_ - trs_t; trs_t = n_; }
+#else
+#define TRS(i)
+#endif
   const int tid = threadIdx.x;
   const int idx = blockIdx.x * PRE_BLOCK + tid;
   const int tiles = gx * gy;
@@ -380,9 +389,11 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scatter_instances(int P, int gx, 
       }
     return;
   }
+  TRS(0)
   for (int y = y0; y < y1; y++)
     for (int x = x0; x < x1; x++) atomicAdd(&cnt[y * gx + x], 1u);
   __syncthreads();
+  TRS(1)
   // reserve this workgroup's slot range in every tile it touches: returning atomics, issued eight at
   // a time so their round trips overlap (one s_waitcnt per batch instead of one per tile)
   for (int t0 = 0; t0 < tiles; t0 += 8 * PRE_BLOCK) {
@@ -401,11 +412,21 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scatter_instances(int P, int gx, 
     }
   }
   __syncthreads();
+  TRS(2)
   for (int y = y0; y < y1; y++)
     for (int x = x0; x < x1; x++) {
       const int c = y * gx + x;
       inst_key[cnt[c] + atomicAdd(&fill[c], 1u)] = key;
     }
+  TRS(3)
+  GSAJ_TRACE_END(scat)
+#ifdef GSAJ_BLOCK_TRACE
+  if ((threadIdx.x & 63) == 0) {
+    unsigned long long *t = g_trace_scat + 4 * (blockIdx.x * (PRE_BLOCK / 64) + (threadIdx.x >> 6));
+    t[2] = (trs_[0] << 32) | trs_[1];
+    t[3] = (trs_[2] << 32) | trs_[3];
+  }
+#endif
 }
 
 // ---- register exchange for the wave-local stages of the tile sort -------------------------------

@@ -38,12 +38,12 @@ def main():
     torch.cuda.synchronize()
     nw = ((W + 15) // 16) * ((H + 15) // 16) * 4
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    for name in ("pre", "fwd", "bwd", "sort", "gbwd"):
+    for name in ("pre", "scat", "fwd", "bwd", "sort", "gbwd"):
         if not hasattr(lib, "gsaj_trace_read_" + name):
             continue
         fn = getattr(lib, "gsaj_trace_read_" + name)
         fn.argtypes, fn.restype = [ctypes.c_void_p, ctypes.c_int], ctypes.c_int
-        n_rec = (P + 63) // 64 if name == "gbwd" else (((P + 255) // 256) * 4 if name == "pre" else nw)
+        n_rec = (P + 63) // 64 if name == "gbwd" else (((P + 255) // 256) * 4 if name in ("pre", "scat") else nw)
         buf = np.zeros((n_rec, 4), np.uint64)
         assert fn(buf.ctypes.data, n_rec) == 0
         np.save(os.path.join(ROOT, "gpurun_out", "block_trace_%s.npy" % name), buf)
@@ -60,6 +60,11 @@ def main():
             print("   preprocess phases per wave (us): per-Gaussian work %.1f  histogram flush + block scan %.1f  drain + ticket %.1f  "
                   "frame scan (last workgroup only; mean / max) %.1f / %.1f" % tuple(
                       [x.astype(np.int64).mean() * 0.01 for x in ph] + [ph[3].astype(np.int64).max() * 0.01]))
+        if name == "scat":
+            lo32 = np.uint64(0xffffffff)
+            ph = [buf[:, 2] >> np.uint64(32), buf[:, 2] & lo32, buf[:, 3] >> np.uint64(32), buf[:, 3] & lo32]
+            print("   scatter phases per wave (us): zero LDS + loads %.1f  LDS count %.1f  reserve (returning atomics) %.1f  stores %.1f" % tuple(
+                x.astype(np.int64).mean() * 0.01 for x in ph))
         if name == "gbwd":
             m21 = np.uint64(0x1fffff)
             a, b = buf[:, 2], buf[:, 3]
