@@ -12,6 +12,32 @@ from gsaj import synthetic as syn
 
 pytestmark = pytest.mark.gpu
 
+CASES_LARGE_IMAGE = [(3000, 2064, 2000, 9)]  # 129 x 125 = 16 125 tiles > LDS_TILES_MAX (8192): global-atomic binning path
+
+
+@pytest.mark.parametrize("case", CASES_LARGE_IMAGE, ids=["P3000_2064x2000"])
+def test_more_tiles_than_the_lds_histogram_holds(case):
+    from gsaj import rasterizer as C
+    from oracle import oracle as orc
+
+    P, W, H, seed = case
+    cam = hp.small_camera(W, H, f=0.9 * W, orthonormal=True)
+    sc = syn.make_scene(P, seed, cam, z_range=(1.0, 4.0), log_scale_range=(math.log(0.004), math.log(0.05)), sh_coeffs=4, margin=0.1)
+    (ref, st), kw = hp.oracle_forward(cam, sc, 1)
+    out, args = hp.gpu_forward(cam, sc, 1, kw=kw)
+    R, color, radii, geom, binning, img, depth, opacity, n_touched = out
+    assert R == ref["num_rendered"]
+    dbg = {k: v.cpu().numpy() for k, v in C.debug_export(P, R, W, H, geom, binning, img).items()}
+    np.testing.assert_array_equal(dbg["point_list"].astype(np.uint32), st["point_list"])
+    np.testing.assert_array_equal(dbg["ranges"], st["ranges"])
+    hp.assert_image_close(color.cpu().numpy(), ref["color"], 2e-4)
+    dLc, dLd = hp.seeds(cam, seed=seed)
+    gref = orc.backward(st, dLc, dLd, cam["projmatrix_raw"])
+    g = hp.gpu_backward(cam, 1, out, args, dLc, dLd)
+    assert hp.rel_err(g[3].cpu().numpy().reshape(gref["dL_dmean3D"].shape), gref["dL_dmean3D"]) < 3e-3
+    assert hp.rel_err(g[9].cpu().numpy(), gref["dL_dtau_sum"]) < 3e-3
+
+
 CASES = [
     # P, W, H, seed, deg, coeffs, z_range, log_scale_range, opacity_range, orthonormal
     (1, 33, 17, 1, 0, 1, (1.0, 1.5), (math.log(0.05), math.log(0.1)), (0.5, 0.9), True),
