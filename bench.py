@@ -137,6 +137,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
+    t_enqueued = time.perf_counter() - t0  # host time to enqueue the K steps (the GPU runs behind it)
     fence()
     elapsed = time.perf_counter() - t0
     for c in ctxs:
@@ -205,6 +206,7 @@ def main():
                                    "algorithmic_bytes": gb_bytes}},
             "single_stream": {"ms_per_step": 1e3 * elapsed_single / a.steps, "value_rank0": inter * a.steps / elapsed_single,
                               "note": "same K steps, one frame at a time on one HIP stream (sequential tracking iterations)"},
+            "host_enqueue_ms_per_step": 1e3 * t_enqueued / a.steps,
             "stage_ms_per_step": {k: v / a.steps for k, v in prof.ms.items() if prof.launches[k]},
         }
         for k in ("k_render_fwd", "k_gaussian_bwd"):

@@ -503,7 +503,11 @@ __global__ __launch_bounds__(256) void k_tile_sort_records(int gx, int gy, const
   const uint32_t beg = im.tile_offset[tile * TILE_REP], end = im.tile_offset[(tile + 1) * TILE_REP];
   const int n = (int)(end - beg);
   if (tid == 0) im.ranges[tile] = n > 0 ? make_uint2(beg, end) : make_uint2(0u, 0u);
-  if (n == 0 || n > cap) return;  // (n > cap: the frame has been flagged by frame_scan / the host chose the global sort)
+  if (n > cap) {  // cannot happen with the max_tile_list of gsaj_forward_num_rendered / a frame_scan-checked capacity
+    if (tid == 0) atomicOr(&im.counters[1], ERR_TILE_LIST);
+    return;
+  }
+  if (n == 0) return;
   int m = 2;
   while (m < n) m <<= 1;
   for (int i = tid; i < m; i += 256) keys[i] = i < n ? inst_key[beg + i] : ~0ull;
