@@ -16,22 +16,24 @@
 //      d/dmean2D ~ w * (conic . d),  d/dconic ~ w * d d^T,  d/dopacity = w / o,  d/dcolour = u * dL/dC,
 //      d/ddepth = u * dL/dD.        (w, u) go to LDS, one 64-pixel row per entry.
 //  phase 2 (lane = (entry slot, pixel row)):  8 slots x 8 pixel rows = 64 lanes.  Each lane walks
-//    the 8 pixels of its row, accumulating the 6 moments of w (1, dx, dy, dx^2, dx dy, dy^2) and
-//    the 4 products u * seed; the 8 rows of a slot are then combined with three register-merge
-//    steps (v_permlane32_swap, v_permlane16_swap, one DPP rotation).  ~21 plain VALU per entry,
-//    against ~29 cross-lane instructions (~80 plain-VALU issue slots, measured) for reducing the 10
-//    partials of every entry across the wave directly.
+//    the 8 pixels of its row with three running sums of w (1, x', x'^2 about the quadrant's centre
+//    column -- dy is constant along a row and dx = ax - x', so these give every second moment about
+//    the Gaussian's mean) and the 4 products u * seed; the 8 rows of a slot are then combined with
+//    three register-merge steps (v_permlane32_swap, v_permlane16_swap, one DPP rotation) -- against
+//    ~29 cross-lane instructions (~80 plain-VALU issue slots, measured) for reducing the 10 partials
+//    of every entry across the wave directly.
 //
 //  No global atomics: the four waves of a tile write per-entry totals to private LDS slots, and
 //  after each round the workgroup stores one 48-byte partial-gradient row per (tile, Gaussian)
 //  instance at the instance's emission slot.  The per-Gaussian kernel (gaussian_bwd.hip) sums a
 //  Gaussian's rows in a fixed order, so gradients are bit-reproducible run to run (the reference's
 //  float atomics are not).  Entries beyond the quadrant's / tile's furthest last-contributor are
-//  never visited.
+//  never visited; those beyond the tile's get a one-byte `reached = 0` flag instead of a zero row.
+//  Workgroups take tiles in reverse order of the forward's finish list (longest tiles first).
 #include "gsaj_common.h"
 #include "wave_reduce.h"
 
-#define BWD_ROUND 56   // list entries staged per workgroup round (LDS <= 32 KB: five workgroups per CU)
+#define BWD_ROUND 56   // list entries staged per workgroup round (32.5 KB LDS, 96 VGPRs: four resident workgroups per CU + headroom)
 #define SLOTS 8        // accepted entries per phase-2 batch
 #define WU_STRIDE 65   // float2 per slot row (64 pixels + 1: conflict-free ds_read_b64 in phase 2)
 #define ACC_C 10       // partials per (entry, wave)

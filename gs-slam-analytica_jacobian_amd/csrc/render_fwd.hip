@@ -3,15 +3,16 @@
 // Semantics: forward.cu:406-535 (renderCUDA): power > 0 skipped, alpha = min(0.99, o*exp(power)),
 // alpha < 1/255 skipped, stop before T(1-alpha) < 1e-4, n_touched counts T(1-alpha) > 0.5.
 //
-// MI355X mapping: one 256-thread workgroup per 16x16 tile = four wave64s, each owning an
-// 8x8 pixel quadrant (one pixel per lane).  Each wave stages 64 sorted 48-byte instance
-// records at a time in its private LDS area with coalesced loads; the entry loop reads them
-// back as wave-uniform (broadcast) ds_read_b128s.  All early-outs are wave-level ballots -- a quadrant whose
-// 64 pixels have all saturated stops walking the list, and entries that no lane of the
-// quadrant accepts skip the colour fetch -- instead of the reference's block-wide votes.
-// n_touched is accumulated into one register per 64 entries (lane l counts entry l) and flushed
-// with ONE atomic wave-instruction per 64 entries (the reference issues one atomic per
-// pixel per entry, forward.cu:512-514).
+// MI355X mapping: one 256-thread workgroup per 16x16 tile = four wave64s, each owning an 8x8 pixel quadrant (one
+// pixel per lane) and walking the tile list on its own -- no workgroup barrier in the loop.  Per 64 sorted 48-byte
+// records: coalesced fetch (the next chunk is requested before the current one is composited), a lane-parallel test
+// of entry l against the quadrant box (wave_reduce.h), and the survivors PACKED in list order into the wave's LDS area
+// with the conic pre-scaled for v_exp_f32.  The entry loop is straight-line, two entries per step, the next step's
+// records requested from LDS before this step's arithmetic; a pixel that skips an entry runs the same arithmetic with
+// weight 0 instead of branching.  Early-outs are wave-level ballots (a quadrant whose 64 pixels have all saturated
+// stops), not the reference's block-wide votes.  n_touched: lane l counts packed entry l, only while some pixel of the
+// quadrant still has T > 0.5, and ONE atomic wave-instruction per 64 entries flushes it (the reference issues one
+// atomic per pixel per entry, forward.cu:512-514).  The order in which tiles finish is recorded for the backward.
 #include "gsaj_common.h"
 #include "wave_reduce.h"
 
