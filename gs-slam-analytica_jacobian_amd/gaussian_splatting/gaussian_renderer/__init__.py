@@ -16,80 +16,62 @@ from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianR
 from gaussian_splatting.utils.sh_utils import eval_sh
 
 
-def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None, mask=None):
-    """Render the scene.  Background tensor (bg_color) must be on the GPU."""
-    xyz = pc.get_xyz
-    if xyz.shape[0] == 0:
-        return None
+_RESULT_KEYS = ("render", "viewspace_points", "visibility_filter", "radii", "depth", "opacity", "n_touched")
 
-    # zero tensor whose .grad receives dL/dmean2D (densification reads viewspace_points.grad[:, :2])
-    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True) + 0
+
+def _settings_for(cam, pc, bg, scale_mod):
+    half_x, half_y = 0.5 * cam.FoVx, 0.5 * cam.FoVy
+    return GaussianRasterizationSettings(int(cam.image_height), int(cam.image_width), math.tan(half_x), math.tan(half_y), bg,
+                                         scale_mod, cam.world_view_transform, cam.full_proj_transform, cam.projection_matrix,
+                                         pc.active_sh_degree, cam.camera_center, False, False)
+
+
+def _python_colours(pc, cam, xyz):
+    """pipe.convert_SHs_python: evaluate the SH colours on the host side of the rasteriser (reference :103-113)."""
+    coeffs = pc.get_features
+    per_channel = coeffs.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
+    view_dir = xyz - cam.camera_center.repeat(coeffs.shape[0], 1)
+    view_dir = view_dir / view_dir.norm(dim=1, keepdim=True)
+    return torch.clamp_min(eval_sh(pc.active_sh_degree, per_channel, view_dir) + 0.5, 0.0)
+
+
+def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None, mask=None):
+    """Render the Gaussians of `pc` from `viewpoint_camera`; `bg_color` lives on the device.  None for an empty model."""
+    xyz = pc.get_xyz
+    n_gauss = xyz.shape[0]
+    if n_gauss == 0:
+        return None
+    # its .grad receives dL/dmean2D: densification reads viewspace_points.grad[:, :2] (gaussian_model.py:767-771)
+    screen_pts = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True) + 0
     try:
-        screenspace_points.retain_grad()
+        screen_pts.retain_grad()
     except Exception:
         pass
 
-    raster_settings = GaussianRasterizationSettings(
-        image_height=int(viewpoint_camera.image_height),
-        image_width=int(viewpoint_camera.image_width),
-        tanfovx=math.tan(viewpoint_camera.FoVx * 0.5),
-        tanfovy=math.tan(viewpoint_camera.FoVy * 0.5),
-        bg=bg_color,
-        scale_modifier=scaling_modifier,
-        viewmatrix=viewpoint_camera.world_view_transform,
-        projmatrix=viewpoint_camera.full_proj_transform,
-        projmatrix_raw=viewpoint_camera.projection_matrix,
-        sh_degree=pc.active_sh_degree,
-        campos=viewpoint_camera.camera_center,
-        prefiltered=False,
-        debug=False,
-    )
-    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
-
-    means3D, means2D, opacity = xyz, screenspace_points, pc.get_opacity
-
-    scales = rotations = cov3D_precomp = None
+    geometry = {"scales": None, "rotations": None, "cov3D_precomp": None}
     if pipe.compute_cov3D_python:
-        cov3D_precomp = pc.get_covariance(scaling_modifier)
+        geometry["cov3D_precomp"] = pc.get_covariance(scaling_modifier)
     else:
-        scales = pc.get_scaling
-        if scales.shape[-1] == 1:  # isotropic model stores one scale per Gaussian
-            scales = scales.repeat(1, 3)
-        rotations = pc.get_rotation
-
-    shs = colors_precomp = None
+        s = pc.get_scaling
+        geometry["scales"] = s.repeat(1, 3) if s.shape[-1] == 1 else s  # an isotropic model stores one scale per Gaussian
+        geometry["rotations"] = pc.get_rotation
+    colour = {"shs": None, "colors_precomp": None}
     if override_color is not None:
-        colors_precomp = override_color
+        colour["colors_precomp"] = override_color
     elif pipe.convert_SHs_python:
-        feats = pc.get_features
-        shs_view = feats.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
-        dir_pp = xyz - viewpoint_camera.camera_center.repeat(feats.shape[0], 1)
-        dir_pp = dir_pp / dir_pp.norm(dim=1, keepdim=True)
-        colors_precomp = torch.clamp_min(eval_sh(pc.active_sh_degree, shs_view, dir_pp) + 0.5, 0.0)
+        colour["colors_precomp"] = _python_colours(pc, viewpoint_camera, xyz)
     else:
-        shs = pc.get_features
+        colour["shs"] = pc.get_features
 
-    def sel(t):
-        return t if (t is None or mask is None) else t[mask]
-
-    rendered_image, radii, depth, opacity_img, n_touched = rasterizer(
-        means3D=sel(means3D), means2D=sel(means2D), shs=sel(shs), colors_precomp=sel(colors_precomp),
-        opacities=sel(opacity), scales=sel(scales), rotations=sel(rotations), cov3D_precomp=sel(cov3D_precomp),
-        theta=viewpoint_camera.cam_rot_delta, rho=viewpoint_camera.cam_trans_delta)
-
+    per_gaussian = dict(means3D=xyz, means2D=screen_pts, opacities=pc.get_opacity, **geometry, **colour)
     if mask is not None:
-        full_r = torch.zeros(xyz.shape[0], dtype=radii.dtype, device=radii.device)
-        full_n = torch.zeros(xyz.shape[0], dtype=n_touched.dtype, device=n_touched.device)
-        full_r[mask], full_n[mask] = radii, n_touched
-        radii, n_touched = full_r, full_n
-
-    # Gaussians that were frustum-culled or had radius 0 were not visible
-    return {
-        "render": rendered_image,
-        "viewspace_points": screenspace_points,
-        "visibility_filter": radii > 0,
-        "radii": radii,
-        "depth": depth,
-        "opacity": opacity_img,
-        "n_touched": n_touched,
-    }
+        per_gaussian = {k: (v if v is None else v[mask]) for k, v in per_gaussian.items()}
+    image, radii, depth, opacity_img, n_touched = GaussianRasterizer(
+        raster_settings=_settings_for(viewpoint_camera, pc, bg_color, scaling_modifier))(
+            theta=viewpoint_camera.cam_rot_delta, rho=viewpoint_camera.cam_trans_delta, **per_gaussian)
+    if mask is not None:  # scatter the per-Gaussian integer outputs back to full length
+        full = [torch.zeros(n_gauss, dtype=t.dtype, device=t.device) for t in (radii, n_touched)]
+        full[0][mask], full[1][mask] = radii, n_touched  # (boolean mask or index tensor)
+        radii, n_touched = full
+    # radius 0 = frustum-culled or degenerate: not visible
+    return dict(zip(_RESULT_KEYS, (image, screen_pts, radii > 0, radii, depth, opacity_img, n_touched)))

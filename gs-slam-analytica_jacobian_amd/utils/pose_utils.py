@@ -5,10 +5,9 @@ import torch
 
 
 def rt2mat(R, T):
-    mat = np.eye(4)
-    mat[0:3, 0:3] = R
-    mat[0:3, 3] = T
-    return mat
+    out = np.eye(4)
+    out[:3, :3], out[:3, 3] = R, T
+    return out
 
 
 def skew_sym_mat(x):
@@ -46,14 +45,13 @@ def SE3_exp(tau):
 
 
 def update_pose(camera, converged_threshold=1e-4):
-    """Apply the accumulated pose delta to the camera, zero the deltas, report convergence."""
-    tau = torch.cat([camera.cam_trans_delta, camera.cam_rot_delta], axis=0)
-    T_w2c = torch.eye(4, device=tau.device)
-    T_w2c[0:3, 0:3] = camera.R
-    T_w2c[0:3, 3] = camera.T
-    new_w2c = SE3_exp(tau) @ T_w2c
-    converged = tau.norm() < converged_threshold
-    camera.update_RT(new_w2c[0:3, 0:3], new_w2c[0:3, 3])
-    camera.cam_rot_delta.data.fill_(0)
-    camera.cam_trans_delta.data.fill_(0)
-    return converged
+    """W2C <- Exp([rho, theta]) W2C with the camera's accumulated deltas, which are then reset; returns |tau| < threshold."""
+    tau = torch.cat((camera.cam_trans_delta, camera.cam_rot_delta))
+    pose = torch.eye(4, device=tau.device)
+    pose[:3, :3], pose[:3, 3] = camera.R, camera.T
+    pose = SE3_exp(tau) @ pose
+    small = tau.norm() < converged_threshold
+    camera.update_RT(pose[:3, :3], pose[:3, 3])
+    for delta in (camera.cam_rot_delta, camera.cam_trans_delta):
+        delta.data.zero_()
+    return small
