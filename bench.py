@@ -38,8 +38,8 @@ PEAK_HBM_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=120)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=480)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg5"])
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg (rank 0, N=1)")
