@@ -33,7 +33,7 @@
 #include "gsaj_common.h"
 #include "wave_reduce.h"
 
-#define BWD_ROUND 56   // list entries staged per workgroup round (32.5 KB LDS, 96 VGPRs: four resident workgroups per CU + headroom)
+#define BWD_ROUND 48   // list entries staged per workgroup round: 30.8 KB LDS + 96 VGPRs = five resident workgroups per CU (all 1200 tiles of a 640x480 frame at once)
 #define SLOTS 8        // accepted entries per phase-2 batch
 #define WU_STRIDE 65   // float2 per slot row (64 pixels + 1: conflict-free ds_read_b64 in phase 2)
 #define ACC_C 10       // partials per (entry, wave)

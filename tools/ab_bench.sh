@@ -2,7 +2,7 @@
 # usage (GPU box): tools/ab_bench.sh name1 name2 ...   -- benches tools/ab_<name>.so variants, two runs each
 for rep in 1 2; do
 for n in "$@"; do
-  GSAJ_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab_$n.so timeout -k 10 120 python bench.py --no-cpu-baseline --steps 80 > gpurun_out/ab_$n.json 2> gpurun_out/ab_$n.err || { echo "$n FAILED"; tail -3 gpurun_out/ab_$n.err; exit 1; }
+  GSAJ_LIB_PATH=$GRAFT_REPO_ROOT/tools/ab_$n.so timeout -k 10 120 python bench.py --no-cpu-baseline --steps 480 > gpurun_out/ab_$n.json 2> gpurun_out/ab_$n.err || { echo "$n FAILED"; tail -3 gpurun_out/ab_$n.err; exit 1; }
   python - "$n" <<'PY'
 import json, sys
 d = json.load(open("gpurun_out/ab_%s.json" % sys.argv[1]))
