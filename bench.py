@@ -176,6 +176,8 @@ def main():
         t_bwd = prof.ms["render_bwd"] / n * 1e-3
         t_fwd = prof.ms["render_fwd"] / max(prof.launches["render_fwd"], 1) * 1e-3
         t_gb = prof.ms["gaussian_bwd"] / max(prof.launches["gaussian_bwd"], 1) * 1e-3
+        t_pre = prof.ms["preprocess"] / max(prof.launches["preprocess"], 1) * 1e-3
+        pre_bytes = P * ((12 + 4 + 12 + 16 + shf_in(M)) + (4 + 8 + 24 + 16 + 12 + 3 + 4 + 4 + 4 + 48))
         ach = FLOP_BWD * inter / t_bwd / 1e12 if t_bwd > 0 else 0.0
         shf = 3 * M * 4
         gb_bytes = P * ((12 + 24 + 4 + 16 + 12 + shf + 12 + 16 + 3) + (12 + 16 + 4 + 12 + 4 + 12 + 24 + shf + 12 + 16)) + R * (48 + 4)
@@ -201,6 +203,8 @@ def main():
             "roofline_other": {
                 "k_render_fwd": {"bound": "mfma", "achieved": FLOP_FWD * inter / t_fwd / 1e12 if t_fwd > 0 else 0.0,
                                  "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "avg_launch_ms": t_fwd * 1e3},
+                "k_preprocess": {"bound": "hbm", "achieved": pre_bytes / t_pre / 1e9 if t_pre > 0 else 0.0, "peak": PEAK_HBM_GBS,
+                                 "unit": "GB/s", "avg_launch_ms": t_pre * 1e3, "algorithmic_bytes": pre_bytes},
                 "k_gaussian_bwd": {"bound": "hbm", "achieved": gb_bytes / t_gb / 1e9 if t_gb > 0 else 0.0,
                                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "avg_launch_ms": t_gb * 1e3,
                                    "algorithmic_bytes": gb_bytes}},
@@ -209,7 +213,7 @@ def main():
             "host_enqueue_ms_per_step": 1e3 * t_enqueued / a.steps,
             "stage_ms_per_step": {k: v / a.steps for k, v in prof.ms.items() if prof.launches[k]},
         }
-        for k in ("k_render_fwd", "k_gaussian_bwd"):
+        for k in ("k_render_fwd", "k_preprocess", "k_gaussian_bwd"):
             o = out["roofline_other"][k]
             o["frac"] = o["achieved"] / o["peak"]
         if world == 1 and not a.no_cpu_baseline:
@@ -217,6 +221,11 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def shf_in(M):
+    """bytes of SH coefficients per Gaussian (fp32, 3 channels)."""
+    return 3 * M * 4
 
 
 def pmc_traffic(kernel):
