@@ -160,18 +160,18 @@ __global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g
   uint8_t cl[3] = {0, 0, 0};
   if (p.shs) {
     cl[0] = g.clamped[3 * ii]; cl[1] = g.clamped[3 * ii + 1]; cl[2] = g.clamped[3 * ii + 2];
-    // coalesced load of this workgroup's contiguous [GB_BLOCK][M*3] SH block, 12 loads per batch
+    // coalesced load of this workgroup's contiguous [GB_BLOCK][M*3] SH block, 24 loads in flight per batch
     const size_t base = (size_t)blockIdx.x * GB_BLOCK * shw;
     const int count = min(GB_BLOCK, p.P - blockIdx.x * GB_BLOCK) * shw;
-    for (int e0 = 0; e0 < count; e0 += 12 * GB_BLOCK) {
-      float v[12];
+    for (int e0 = 0; e0 < count; e0 += 24 * GB_BLOCK) {
+      float v[24];
 #pragma unroll
-      for (int b = 0; b < 12; b++) {
+      for (int b = 0; b < 24; b++) {
         const int e = e0 + b * GB_BLOCK + tid;
         v[b] = e < count ? p.shs[base + e] : 0.f;
       }
 #pragma unroll
-      for (int b = 0; b < 12; b++) {
+      for (int b = 0; b < 24; b++) {
         const int e = e0 + b * GB_BLOCK + tid;
         if (e < count) {
           const int gi = e / shw, k = e - gi * shw;
