@@ -313,3 +313,28 @@ def test_async_forward_matches_sync_and_reports_overflow(torch_cuda):
     ctx2.forward(**args, sync=False)
     with pytest.raises(_lib.GsajError, match="tile list|aborted"):
         ctx2.status()
+
+
+def test_mark_visible_matches_oracle(torch_cuda):
+    """GaussianRasterizer.markVisible (in_frustum: view-space z > 0.2, auxiliary.h:139-164) against the oracle, on points
+    in front of, behind and right at the near threshold of the camera."""
+    import torch
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from oracle import oracle as orc
+
+    cam = hp.small_camera(160, 120, orthonormal=True)
+    rng = np.random.default_rng(3)
+    w2c = np.asarray(cam["w2c"], np.float64)
+    pc = np.concatenate([rng.uniform(-2, 2, (4000, 2)), rng.uniform(-1.0, 3.0, (4000, 1))], axis=1)   # camera-frame points
+    pc[:50, 2] = 0.2 + rng.uniform(-1e-3, 1e-3, 50)                                                       # around the threshold
+    pw = ((np.linalg.inv(w2c) @ np.concatenate([pc, np.ones((4000, 1))], axis=1).T).T[:, :3]).astype(np.float32)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)  # noqa: E731
+    st = GaussianRasterizationSettings(image_height=120, image_width=160, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"],
+                                       bg=torch.zeros(3, device=dev), scale_modifier=1.0, viewmatrix=t(cam["viewmatrix"]),
+                                       projmatrix=t(cam["projmatrix"]), projmatrix_raw=t(cam["projmatrix_raw"]), sh_degree=0,
+                                       campos=t(cam["campos"]), prefiltered=False, debug=False)
+    got = GaussianRasterizer(st).markVisible(t(pw)).cpu().numpy().astype(bool)
+    want = orc.mark_visible(pw, cam["viewmatrix"]).astype(bool)
+    assert got.shape == want.shape and 500 < want.sum() < 3500
+    np.testing.assert_array_equal(got, want)
