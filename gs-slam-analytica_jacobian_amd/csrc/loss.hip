@@ -12,6 +12,7 @@
 #include "gsaj_common.h"
 
 #define LOSS_BLOCK 256
+#define LOSS_PPT 4  // pixels per thread (strided by the workgroup size: coalesced, 4x the loads in flight, 4x fewer partials)
 
 struct LossParams {
   int W, H, flags;
@@ -31,12 +32,14 @@ __global__ __launch_bounds__(LOSS_BLOCK) void k_loss_seeds(LossParams p) {
   __shared__ float red[4][LOSS_BLOCK / 64];
   __shared__ bool is_last;
   const size_t HW = (size_t)p.W * p.H;
-  const size_t pix = (size_t)blockIdx.x * LOSS_BLOCK + threadIdx.x;
   const bool tracking = p.flags & GSAJ_LOSS_TRACKING, mono = p.flags & GSAJ_LOSS_MONOCULAR, noexp = p.flags & GSAJ_LOSS_NO_EXPOSURE;
   const float ea = noexp ? 1.f : expf(p.exp_a[0]), eb = noexp ? 0.f : p.exp_b[0];
   const float k_rgb = (mono ? 1.f : p.alpha) / (3.f * (float)HW), k_d = (1.f - p.alpha) / (float)HW;
   float s_rgb = 0.f, s_d = 0.f, s_a = 0.f, s_b = 0.f;
-  if (pix < HW) {
+#pragma unroll
+  for (int q = 0; q < LOSS_PPT; q++) {
+    const size_t pix = ((size_t)blockIdx.x * LOSS_PPT + q) * LOSS_BLOCK + threadIdx.x;
+    if (pix >= HW) continue;
     const float g0 = p.gt_color[pix], g1 = p.gt_color[HW + pix], g2 = p.gt_color[2 * HW + pix];
     const float c0 = p.color[pix], c1 = p.color[HW + pix], c2 = p.color[2 * HW + pix];
     const float op = p.opacity[pix];
@@ -46,20 +49,20 @@ __global__ __launch_bounds__(LOSS_BLOCK) void k_loss_seeds(LossParams p) {
     const float r0 = (ea * c0 + eb) * m - g0 * m, r1 = (ea * c1 + eb) * m - g1 * m, r2 = (ea * c2 + eb) * m - g2 * m;
     const float a0 = fabsf(r0), a1 = fabsf(r1), a2 = fabsf(r2);
     const float t0 = wrgb * m * sgn(r0), t1 = wrgb * m * sgn(r1), t2 = wrgb * m * sgn(r2);
-    s_rgb = wrgb * (a0 + a1 + a2);
+    s_rgb += wrgb * (a0 + a1 + a2);
     p.dL_dcolor[pix] = k_rgb * ea * t0;
     p.dL_dcolor[HW + pix] = k_rgb * ea * t1;
     p.dL_dcolor[2 * HW + pix] = k_rgb * ea * t2;
     if (p.dL_dopacity) p.dL_dopacity[pix] = tracking ? k_rgb * (a0 + a1 + a2) : 0.f;
-    s_a = ea * (t0 * c0 + t1 * c1 + t2 * c2);
-    s_b = t0 + t1 + t2;
+    s_a += ea * (t0 * c0 + t1 * c1 + t2 * c2);
+    s_b += t0 + t1 + t2;
     float dd = 0.f;
     if (!mono) {
       const float gd = p.gt_depth[pix], d = p.depth[pix];
       float dm = (gd > 0.01f) ? 1.f : 0.f;
       if (tracking) dm = (op > 0.95f) ? dm : 0.f;
       const float rd = d * dm - gd * dm;
-      s_d = fabsf(rd);
+      s_d += fabsf(rd);
       dd = k_d * dm * sgn(rd);
     }
     p.dL_ddepth[pix] = dd;
@@ -95,10 +98,21 @@ __global__ __launch_bounds__(LOSS_BLOCK) void k_loss_seeds(LossParams p) {
   if (!is_last) return;
   __shared__ double fin[4][LOSS_BLOCK / 64];
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
-  for (unsigned b = threadIdx.x; b < gridDim.x; b += LOSS_BLOCK) {
+  for (unsigned b0 = threadIdx.x; b0 < gridDim.x; b0 += 4 * LOSS_BLOCK) {  // unconditional loads, 16 in flight, masked afterwards
+    float t[4][4];
 #pragma unroll
-    for (int c = 0; c < 4; c++)
-      acc[c] += (double)__hip_atomic_load(&p.partials[(size_t)b * 4 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int u = 0; u < 4; u++) {
+      const unsigned b = b0 + u * LOSS_BLOCK, bc = min(b, gridDim.x - 1);
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const float x = __hip_atomic_load(&p.partials[(size_t)bc * 4 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t[u][c] = b < gridDim.x ? x : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+      for (int c = 0; c < 4; c++) acc[c] += (double)t[u][c];
   }
 #pragma unroll
   for (int c = 0; c < 4; c++) {
@@ -128,7 +142,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void k_loss_seeds(LossParams p) {
 }
 
 extern "C" size_t gsaj_loss_workspace_bytes(int W, int H) {
-  const size_t nblk = ((size_t)W * H + LOSS_BLOCK - 1) / LOSS_BLOCK;
+  const size_t nblk = ((size_t)W * H + LOSS_BLOCK * LOSS_PPT - 1) / (LOSS_BLOCK * LOSS_PPT);
   return 256 + nblk * 4 * sizeof(float) + 256;
 }
 
@@ -152,7 +166,7 @@ extern "C" int gsaj_loss_seeds(int W, int H, int flags, float alpha, float rgb_b
   p.ticket = (uint32_t *)base;          // the caller zeroes the workspace once, when it allocates it
   p.partials = (float *)(base + 256);
   p.out = out_scalars;
-  const unsigned nblk = (unsigned)(((size_t)W * H + LOSS_BLOCK - 1) / LOSS_BLOCK);
+  const unsigned nblk = (unsigned)(((size_t)W * H + LOSS_BLOCK * LOSS_PPT - 1) / (LOSS_BLOCK * LOSS_PPT));
   hipLaunchKernelGGL(k_loss_seeds, dim3(nblk), dim3(LOSS_BLOCK), 0, (hipStream_t)stream, p);
   GSAJ_HIP_CHECK(hipGetLastError());
   return GSAJ_OK;
