@@ -289,13 +289,17 @@ int gsaj_rasterize_backward(int P, int D, int M, int R, const float *bg, int W, 
                             float *dL_dopacity, float *dL_dcolor, float *dL_ddepth, float *dL_dmean3D,
                             float *dL_dcov3D, float *dL_dsh, float *dL_dscale, float *dL_drot, float *dL_dtau,
                             float *dL_dtau_sum, void *stream) {
+  // pose-only mode (tracking: only the camera is optimised): every per-Gaussian output pointer NULL, dL_dtau_sum given
+  const bool pose_only = !dL_dmean2D && !dL_dconic && !dL_dopacity && !dL_dcolor && !dL_ddepth && !dL_dmean3D && !dL_dcov3D &&
+                         !dL_dsh && !dL_dscale && !dL_drot && dL_dtau_sum;
   if (P <= 0 || R < 0 || W <= 0 || H <= 0 || !bg || !means3D || !viewmatrix || !projmatrix || !projmatrix_raw ||
-      !geom_ws || !binning_ws || !image_ws || !dL_dpix || !dL_dpix_depth || !dL_dmean2D || !dL_dconic ||
-      !dL_dopacity || !dL_dcolor || !dL_ddepth || !dL_dmean3D || !dL_dcov3D) {
+      !geom_ws || !binning_ws || !image_ws || !dL_dpix || !dL_dpix_depth ||
+      (!pose_only && (!dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_ddepth || !dL_dmean3D || !dL_dcov3D))) {
     gsaj_set_error("gsaj_rasterize_backward: invalid argument");
     return GSAJ_ERR_INVALID_ARGUMENT;
   }
-  if ((shs && (!dL_dsh || !campos)) || (scales && (!rotations || !dL_dscale || !dL_drot)) || (!scales && !cov3D_precomp)) {
+  if ((shs && ((!pose_only && !dL_dsh) || !campos)) || (scales && (!rotations || (!pose_only && (!dL_dscale || !dL_drot)))) ||
+      (!scales && !cov3D_precomp)) {
     gsaj_set_error("gsaj_rasterize_backward: missing gradient buffer for a provided input");
     return GSAJ_ERR_INVALID_ARGUMENT;
   }

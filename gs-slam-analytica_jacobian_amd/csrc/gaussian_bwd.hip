@@ -338,7 +338,7 @@ __global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g
     }
     o_m2x = g2x; o_m2y = g2y; o_ca = gcx; o_cb = gcy; o_cc = gcz; o_op = gop; o_col = gcol; o_dz = gz; o_gm = gm;
     // ---- 6. cov3D -> scale, rotation ----
-    if (p.scales) {
+    if (p.scales && p.dL_dscale) {  // (skipped in pose-only mode)
       const float r = q.x, x = q.y, y = q.z, z = q.w;
       const float R[3][3] = {{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
                              {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g
   }
   TRM(3)
   // ---- 9. outputs: one row per Gaussian, zeros for culled ones (the reference's binding memsets first) ----
-  if (idx < p.P) {
+  if (idx < p.P && p.dL_dmean2D) {  // pose-only mode (all per-Gaussian outputs NULL) stores nothing per Gaussian
     const size_t i = (size_t)idx;
     p.dL_dmean2D[3 * i] = o_m2x; p.dL_dmean2D[3 * i + 1] = o_m2y; p.dL_dmean2D[3 * i + 2] = 0.f;
     reinterpret_cast<float4 *>(p.dL_dconic)[i] = make_float4(o_ca, o_cb, 0.f, o_cc);
@@ -437,13 +437,13 @@ __global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g
       p.dL_dscale[3 * i] = o_scale.x; p.dL_dscale[3 * i + 1] = o_scale.y; p.dL_dscale[3 * i + 2] = o_scale.z;
       reinterpret_cast<float4 *>(p.dL_drot)[i] = o_rot;
     }
-    if (p.dL_dtau) {
+  }
+  if (idx < p.P && p.dL_dtau) {
 #pragma unroll
-      for (int k = 0; k < 6; k++) p.dL_dtau[6 * i + k] = tau[k];
-    }
+    for (int k = 0; k < 6; k++) p.dL_dtau[6 * (size_t)idx + k] = tau[k];
   }
   // dL/dSH block: coalesced store (rows of culled Gaussians and coefficients above the active degree are zero)
-  if (p.shs) {
+  if (p.shs && p.dL_dsh) {
     if (!vis) {
       for (int k = 0; k < shw; k++) sh_io[tid * shs_stride + k] = 0.f;
     }

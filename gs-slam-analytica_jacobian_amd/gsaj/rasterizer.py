@@ -335,7 +335,9 @@ class FrameContext:
 
     def backward(self, bg, means3D, viewmatrix, projmatrix, projmatrix_raw, campos, tanfovx, tanfovy, dL_dcolor, dL_ddepth,
                  sh_degree=0, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None,
-                 scale_modifier=1.0, slot=0):
+                 scale_modifier=1.0, slot=0, pose_only=False):
+        """pose_only=True (tracking: only the camera is optimised): the per-Gaussian parameter gradients are neither
+        computed to the end nor stored; only g["tau_sum"] (and g["tau"] if allocated) are valid afterwards."""
         g = self.slots[slot]
         if g["tau_all"] is not None:
             g["tau_all"].zero_()  # rows of the other ranks' keyframes must be zero before the sum all-reduce
@@ -344,9 +346,10 @@ class FrameContext:
             _ptr(colors_precomp), _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp),
             _ptr(viewmatrix), _ptr(projmatrix), _ptr(projmatrix_raw), _ptr(campos), float(tanfovx), float(tanfovy),
             self.radii.data_ptr(), self.geom.data_ptr(), self.binning.data_ptr(), self.img.data_ptr(), _ptr(dL_dcolor),
-            _ptr(dL_ddepth), g["mean2D"].data_ptr(), g["conic"].data_ptr(), g["opacity"].data_ptr(),
-            g["color"].data_ptr(), g["depth"].data_ptr(), g["mean3D"].data_ptr(), g["cov3D"].data_ptr(), _ptr(g["sh"]),
-            _ptr(g["scale"]), _ptr(g["rot"]), _ptr(g["tau"]), g["tau_sum"].data_ptr(), _stream(self.dev)),
+            _ptr(dL_ddepth), *([None] * 10 if pose_only else [
+                g["mean2D"].data_ptr(), g["conic"].data_ptr(), g["opacity"].data_ptr(), g["color"].data_ptr(),
+                g["depth"].data_ptr(), g["mean3D"].data_ptr(), g["cov3D"].data_ptr(), _ptr(g["sh"]), _ptr(g["scale"]),
+                _ptr(g["rot"])]), _ptr(g["tau"]), g["tau_sum"].data_ptr(), _stream(self.dev)),
             "gsaj_rasterize_backward")
         return g
 

@@ -137,6 +137,8 @@ int gsaj_forward_preprocess_cap(int P, int D, int M, int W, int H,
  * dL_dmean3D [P,3], dL_dcov3D [P,6], dL_dsh [P,M,3], dL_dscale [P,3], dL_drot [P,4],
  * dL_dtau [P,6] (may be NULL) and dL_dtau_sum [6] = sum over Gaussians, tau = [rho, theta]
  * (may be NULL; replaces torch.sum in diff_gaussian_rasterization/__init__.py:162).
+ * Pose-only mode (tracking, where only the camera is optimised): pass NULL for ALL ten per-Gaussian outputs
+ * dL_dmean2D .. dL_drot and a dL_dtau_sum; the per-Gaussian parameter gradients are then neither finished nor stored.
  * The three workspaces must be the ones the forward filled. */
 int gsaj_rasterize_backward(int P, int D, int M, int R, const float *bg, int W, int H,
                             const float *means3D, const float *shs, const float *colors_precomp,

@@ -338,3 +338,29 @@ def test_mark_visible_matches_oracle(torch_cuda):
     want = orc.mark_visible(pw, cam["viewmatrix"]).astype(bool)
     assert got.shape == want.shape and 500 < want.sum() < 3500
     np.testing.assert_array_equal(got, want)
+
+
+def test_pose_only_backward_gives_the_same_tau(torch_cuda):
+    """FrameContext.backward(pose_only=True): dL/dtau bit-identical to the full backward, per-Gaussian buffers untouched."""
+    import torch
+    from gsaj.rasterizer import FrameContext
+
+    cam, sc, deg = hp.make("p6000_640x480_sh1")
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)  # noqa: E731
+    P, M = sc["means3D"].shape[0], sc["shs"].shape[1]
+    args = dict(bg=torch.zeros(3, device=dev), means3D=t(sc["means3D"]), opacities=t(sc["opacities"]), viewmatrix=t(cam["viewmatrix"]),
+                projmatrix=t(cam["projmatrix"]), campos=t(cam["campos"]), tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], sh_degree=deg,
+                shs=t(sc["shs"]), scales=t(sc["scales"]), rotations=t(sc["rotations"]))
+    dLc, dLd = hp.seeds(cam, seed=8)
+    bargs = dict(bg=args["bg"], means3D=args["means3D"], viewmatrix=args["viewmatrix"], projmatrix=args["projmatrix"],
+                 projmatrix_raw=t(cam["projmatrix_raw"]), campos=args["campos"], tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"],
+                 dL_dcolor=t(dLc), dL_ddepth=t(dLd), sh_degree=deg, shs=args["shs"], scales=args["scales"], rotations=args["rotations"])
+    ctx = FrameContext(P, cam["W"], cam["H"], M, dev, per_gaussian_tau=True)
+    ctx.forward(**args)
+    g = ctx.backward(**bargs)
+    tau_full, tau_pg = g["tau_sum"].clone(), g["tau"].clone()
+    ctx.bucket.fill_(123.0)
+    g = ctx.backward(**bargs, pose_only=True)
+    assert torch.equal(g["tau_sum"], tau_full) and torch.equal(g["tau"], tau_pg)
+    assert bool((ctx.bucket == 123.0).all())

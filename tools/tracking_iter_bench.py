@@ -23,6 +23,9 @@ class View:
     pass
 
 
+POSE_ONLY = [False]
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
     dev = torch.device("cuda:0")
@@ -113,7 +116,7 @@ def main():
                pt.exposure_a, pt.exposure_b)
         g = ctx.backward(bg=bg, means3D=means, viewmatrix=pt.viewmatrix, projmatrix=pt.projmatrix, projmatrix_raw=proj_raw,
                          campos=pt.campos, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], dL_dcolor=o["dL_dcolor"],
-                         dL_ddepth=o["dL_ddepth"], sh_degree=3, shs=shs, scales=scales, rotations=rots)
+                         dL_ddepth=o["dL_ddepth"], sh_degree=3, shs=shs, scales=scales, rotations=rots, pose_only=POSE_ONLY[0])
         pt.step(g["tau_sum"], ls.scalars[3:5])
 
     # A': the drop-in path with the reference's optimiser step, update_pose and converged read-back (slam_frontend.py:163-193)
@@ -144,6 +147,9 @@ def main():
 
     ms_a, ms_b, ms_c = timed(iter_a), timed(iter_b), timed(iter_c)
     ms_a2, ms_d = timed(iter_a2), timed(iter_d)
+    POSE_ONLY[0] = True
+    ms_d_pose = timed(iter_d)
+    print("D with the pose-only backward (no per-Gaussian parameter gradients): %.3f ms" % ms_d_pose)
     # E: iteration D captured once into a HIP graph (all buffers are persistent) and replayed
     gm8 = v.grad_mask.to(torch.uint8)
     v.grad_mask = gm8
