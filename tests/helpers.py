@@ -100,5 +100,6 @@ def assert_image_close(got, want, tol, flip_fraction=5e-5, flip_bound=0.02):
     want = np.asarray(want, np.float64)
     scale = np.abs(want).max() + 1e-30
     err = np.abs(got - want) / scale
-    assert (err > tol).mean() <= flip_fraction, ((err > tol).sum(), err.max())
+    # (at least one pixel -- three channel values -- is always allowed: small images would otherwise have a budget of zero)
+    assert (err > tol).sum() <= max(3.0, flip_fraction * err.size), ((err > tol).sum(), err.max())
     assert err.max() <= flip_bound, err.max()
