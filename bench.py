@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--sync", action="store_true", help="read the instance count back on the host every frame")
     ap.add_argument("--frames-in-flight", type=int, default=3,
                     help="independent frames (keyframes of a mapping window) processed concurrently, one HIP stream each")
+    ap.add_argument("--records", default="fp32", choices=["fp32", "fp16"],
+                    help="storage of the sorted instance records (fp16: conic / opacity / colour as halves, config 5)")
     ap.add_argument("--sh-coeffs", type=int, default=0, help="experiment: keep only the first N SH coefficients per Gaussian")
     return ap.parse_args()
 
@@ -71,7 +73,9 @@ def main():
 
     from gsaj import synthetic as syn
     from gsaj import keyframe_shard as ks
-    from gsaj.rasterizer import FrameContext, profile_stages
+    from gsaj.rasterizer import FrameContext, profile_stages, set_record_format
+
+    set_record_format(16 if a.records == "fp16" else 32)
 
     cam0, sc = syn.config_scene(a.workload)
     if world > 1:  # one keyframe per rank, on a 0.5 m arc around the cfg camera (cfg4-style window)
@@ -185,7 +189,7 @@ def main():
             "metric": "Gaussian-pixel interactions/sec (fwd+Jacobian), 640x480",
             "value": value, "unit": "interactions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if a.records == "fp32" else "f32 (records stored as f16)", "data": "synthetic",
             "config": {"workload": "%s: %d Gaussians (SH degree %d, %d coeffs), %dx%d, forward splat + analytical "
                                    "Jacobian backward (dL/dmu, dL/dSigma->conic, per-Gaussian grads, dL/dtau)"
                                    % (a.workload, P, deg, M, W, H),

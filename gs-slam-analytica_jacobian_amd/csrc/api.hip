@@ -185,6 +185,17 @@ int gsaj_forward_aborted_count(int W, int H, const void *image_ws, void *stream,
   return GSAJ_OK;
 }
 
+static int g_rec16 = 0;  // process-wide: record storage of the frames launched from now on (gsaj_set_record_format)
+
+int gsaj_set_record_format(int bits) {
+  if (bits != 16 && bits != 32) {
+    gsaj_set_error("gsaj_set_record_format: 16 or 32, got %d", bits);
+    return GSAJ_ERR_INVALID_ARGUMENT;
+  }
+  g_rec16 = bits == 16;
+  return GSAJ_OK;
+}
+
 int gsaj_forward_render(int P, int R, int max_tile_list, int W, int H, const float *bg, const float *colors_precomp,
                         const int *radii,
                         void *geom_ws, void *binning_ws, size_t binning_ws_bytes, void *image_ws, float *out_color,
@@ -212,7 +223,7 @@ int gsaj_forward_render(int P, int R, int max_tile_list, int W, int H, const flo
   int rc;
   if (max_tile_list >= 0 && max_tile_list <= SORT_CAP) {
     // fast path: per-tile lists sorted in LDS
-    if ((rc = launch_tile_binning(P, R, max_tile_list, gx, gy, rad, features, g, b, im, s)) != GSAJ_OK) return rc;
+    if ((rc = launch_tile_binning(P, R, max_tile_list, g_rec16, gx, gy, rad, features, g, b, im, s)) != GSAJ_OK) return rc;
   } else {
     // a tile list exceeds the LDS sort capacity (or the caller forces it with max_tile_list < 0):
     // global radix sort of (tile << 32 | depth) keys, as the reference does
@@ -276,7 +287,7 @@ int gsaj_rasterize_forward_async(int P, int D, int M, const float *bg, int W, in
   const int *rad = radii ? radii : g.internal_radii;
   const float *features = colors_precomp ? colors_precomp : g.rgb;
   const int sort_cap = (tile_list_capacity > 0 && tile_list_capacity < SORT_CAP) ? tile_list_capacity : SORT_CAP;
-  if ((rc = launch_tile_binning(P, capacity, sort_cap, gx, gy, rad, features, g, b, im, s)) != GSAJ_OK) return rc;
+  if ((rc = launch_tile_binning(P, capacity, sort_cap, g_rec16, gx, gy, rad, features, g, b, im, s)) != GSAJ_OK) return rc;
   return launch_render_forward(W, H, gx, gy, bg, b, im, out_color, out_depth, out_opacity, n_touched, s);
 }
 

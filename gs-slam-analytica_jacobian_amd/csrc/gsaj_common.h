@@ -177,7 +177,7 @@ struct FwdParams {
 };
 
 int launch_preprocess(const FwdParams &p, int *radii, int *n_touched, const GeomWS &g, const ImageWS &im, hipStream_t s);
-int launch_tile_binning(int P, int R, int sort_cap, int grid_x, int grid_y, const int *radii, const float *features, const GeomWS &g,
+int launch_tile_binning(int P, int R, int sort_cap, int rec16, int grid_x, int grid_y, const int *radii, const float *features, const GeomWS &g,
                         const BinWS &b, const ImageWS &im, hipStream_t s);
 int launch_emit_keys(int P, int grid_x, int grid_y, const int *radii, const GeomWS &g, const BinWS &b, hipStream_t s);
 int launch_sort(int R, int end_bit, const BinWS &b, hipStream_t s);
@@ -221,6 +221,40 @@ __device__ __forceinline__ void tile_rect(float px, float py, int r, int gx, int
 }
 __device__ __forceinline__ float3 cross3(float3 a, float3 b) {
   return make_float3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+#endif
+
+// ---- instance record formats ------------------------------------------------------------------------------
+// fp32 (default): 3 float4 = {mean x, mean y, depth, id | conic a, b, c, opacity | r, g, b, emission slot}.
+// fp16 storage (gsaj_set_record_format(16); BASELINE config 5 "fp16 splat with fp32 Jacobian accumulation"): 2 float4 =
+// {mean x, mean y, depth, emission slot | half2(a, b), half2(c, opacity), half2(r, g), half2(b, 0)} -- positions, depth and
+// every accumulation stay fp32; conic / opacity / colour are rounded to half once, when the sort kernel writes the
+// record.  The Gaussian id is then taken from point_list.  counters[7] of the frame says which format the records have.
+#define REC16_F4 2
+#ifdef __HIPCC__
+#include <hip/hip_fp16.h>
+__device__ __forceinline__ uint32_t gsaj_pack_h2(float a, float b) {
+  const __half2 h = __floats2half2_rn(a, b);
+  return *reinterpret_cast<const uint32_t *>(&h);
+}
+__device__ __forceinline__ float2 gsaj_unpack_h2(uint32_t u) { return __half22float2(*reinterpret_cast<const __half2 *>(&u)); }
+__device__ __forceinline__ void gsaj_load_record(const float4 *__restrict__ records, const uint32_t *__restrict__ point_list, size_t k,
+                                                 bool rec16, float4 &q0, float4 &q1, float4 &q2) {
+  if (!rec16) {
+    const float4 *s = records + k * REC_F4;
+    q0 = s[0], q1 = s[1], q2 = s[2];
+    return;
+  }
+  const float4 *s = records + k * REC16_F4;
+  const float4 p0 = s[0], p1 = s[1];
+  const float2 ab = gsaj_unpack_h2(__float_as_uint(p1.x)), co = gsaj_unpack_h2(__float_as_uint(p1.y));
+  const float2 rg = gsaj_unpack_h2(__float_as_uint(p1.z)), bz = gsaj_unpack_h2(__float_as_uint(p1.w));
+  q0 = make_float4(p0.x, p0.y, p0.z, point_list ? __uint_as_float(point_list[k]) : 0.f);
+  q1 = make_float4(ab.x, ab.y, co.x, co.y);
+  q2 = make_float4(rg.x, rg.y, bz.x, p0.w);
+}
+__device__ __forceinline__ uint32_t gsaj_record_emission_slot(const float4 *__restrict__ records, size_t k, bool rec16) {
+  return __float_as_uint(rec16 ? records[k * REC16_F4].w : records[k * REC_F4 + 2].w);
 }
 #endif
 

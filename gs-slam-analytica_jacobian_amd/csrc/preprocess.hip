@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256) void k_tile_sort_records(int gx, int gy, const
                                                            const float *__restrict__ features, GeomWS g, ImageWS im,
                                                            const uint64_t *__restrict__ inst_key,
                                                            uint32_t *__restrict__ point_list,
-                                                           float4 *__restrict__ records, int cap) {
+                                                           float4 *__restrict__ records, int cap, int rec16) {
   // `cap` keys of dynamic LDS: the host sizes it to the longest tile list (sync path: known exactly; async path: the
   // caller's tile_list_capacity, checked on the device by frame_scan), so short lists do not pay for 32 KB per workgroup
   extern __shared__ uint64_t keys[];
@@ -503,6 +503,7 @@ __global__ __launch_bounds__(256) void k_tile_sort_records(int gx, int gy, const
   const uint32_t beg = im.tile_offset[tile * TILE_REP], end = im.tile_offset[(tile + 1) * TILE_REP];
   const int n = (int)(end - beg);
   if (tid == 0) im.ranges[tile] = n > 0 ? make_uint2(beg, end) : make_uint2(0u, 0u);
+  if (tid == 0 && tile == 0) im.counters[7] = (uint32_t)rec16;  // record format of this frame (read by the compositors)
   if (n > cap) {  // cannot happen with the max_tile_list of gsaj_forward_num_rendered / a frame_scan-checked capacity
     if (tid == 0) atomicOr(&im.counters[1], ERR_TILE_LIST);
     return;
@@ -564,9 +565,15 @@ __global__ __launch_bounds__(256) void k_tile_sort_records(int gx, int gy, const
     const uint32_t rp = __float_as_uint(a.z);
     const int x0 = (int)(rp & 1023u), y0 = (int)((rp >> 10) & 1023u), w = (int)(rp >> 20);
     const uint32_t u = __float_as_uint(a.w) + (uint32_t)((ty - y0) * w + (tx - x0));
-    records[(size_t)k * REC_F4 + 0] = make_float4(a.x, a.y, __uint_as_float((uint32_t)(key >> 32)), __uint_as_float(id));
-    records[(size_t)k * REC_F4 + 1] = bq;
-    records[(size_t)k * REC_F4 + 2] = make_float4(c.x, c.y, c.z, __uint_as_float(u));
+    if (!rec16) {
+      records[(size_t)k * REC_F4 + 0] = make_float4(a.x, a.y, __uint_as_float((uint32_t)(key >> 32)), __uint_as_float(id));
+      records[(size_t)k * REC_F4 + 1] = bq;
+      records[(size_t)k * REC_F4 + 2] = make_float4(c.x, c.y, c.z, __uint_as_float(u));
+    } else {
+      records[(size_t)k * REC16_F4 + 0] = make_float4(a.x, a.y, __uint_as_float((uint32_t)(key >> 32)), __uint_as_float(u));
+      records[(size_t)k * REC16_F4 + 1] = make_float4(__uint_as_float(gsaj_pack_h2(bq.x, bq.y)), __uint_as_float(gsaj_pack_h2(bq.z, bq.w)),
+                                                      __uint_as_float(gsaj_pack_h2(c.x, c.y)), __uint_as_float(gsaj_pack_h2(c.z, 0.f)));
+    }
   }
   GSAJ_TRACE_END(sort)
 #ifdef GSAJ_BLOCK_TRACE
@@ -623,7 +630,7 @@ int launch_preprocess(const FwdParams &p, int *radii, int *n_touched, const Geom
   return GSAJ_OK;
 }
 
-int launch_tile_binning(int P, int R, int sort_cap, int grid_x, int grid_y, const int *radii, const float *features,
+int launch_tile_binning(int P, int R, int sort_cap, int rec16, int grid_x, int grid_y, const int *radii, const float *features,
                         const GeomWS &g, const BinWS &b, const ImageWS &im, hipStream_t s) {
   (void)R;
   const int nblk = (P + PRE_BLOCK - 1) / PRE_BLOCK;
@@ -639,7 +646,7 @@ int launch_tile_binning(int P, int R, int sort_cap, int grid_x, int grid_y, cons
     int cap = 128;
     while (cap < sort_cap && cap < SORT_CAP) cap <<= 1;
     hipLaunchKernelGGL(k_tile_sort_records, dim3(grid_x * grid_y), dim3(256), sizeof(uint64_t) * (size_t)cap, s, grid_x, grid_y,
-                       radii, features, g, im, b.keys_unsorted, b.point_list, b.records, cap);
+                       radii, features, g, im, b.keys_unsorted, b.point_list, b.records, cap, rec16);
   }
   GSAJ_HIP_CHECK(hipGetLastError());
   return GSAJ_OK;

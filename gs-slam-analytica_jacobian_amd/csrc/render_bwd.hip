@@ -101,16 +101,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
   uint32_t hi = range.x + bmax;  // exclusive sorted position
   // entries [hi, range.y) were never reached by any pixel of the tile: their partials are zero.  Only a one-byte
   // flag says so (opaque scenes leave most of a long list unreached: 48-byte zero rows would be most of the traffic)
-  for (uint32_t k = hi + tid; k < range.y; k += 256) reached[__float_as_uint(records[(size_t)k * REC_F4 + 2].w)] = 0;
+  const bool rec16 = counters[7] != 0u;  // fp16-storage records (gsaj_common.h)
+  for (uint32_t k = hi + tid; k < range.y; k += 256) reached[gsaj_record_emission_slot(records, (size_t)k, rec16)] = 0;
 
   while (hi > range.x) {
     const uint32_t lo = (hi - range.x > BWD_ROUND) ? hi - BWD_ROUND : range.x;
     const int n = (int)(hi - lo);
     if (tid < n) {
-      const float4 *src = records + (size_t)(lo + tid) * REC_F4;
-      rec[tid * REC_F4 + 0] = src[0];
-      rec[tid * REC_F4 + 1] = src[1];
-      rec[tid * REC_F4 + 2] = src[2];
+      float4 q0, q1, q2;
+      gsaj_load_record(records, nullptr, (size_t)(lo + tid), rec16, q0, q1, q2);
+      rec[tid * REC_F4 + 0] = q0;
+      rec[tid * REC_F4 + 1] = q1;
+      rec[tid * REC_F4 + 2] = q2;
     }
     {
       float4 *z = reinterpret_cast<float4 *>(acc);

@@ -26,7 +26,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                                                     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                                                     float *__restrict__ out_color, float *__restrict__ out_depth,
                                                     float *__restrict__ out_opacity, int *__restrict__ n_touched,
-                                                    uint32_t *__restrict__ counters, uint32_t *__restrict__ finish_list) {
+                                                    uint32_t *__restrict__ counters, uint32_t *__restrict__ finish_list,
+                                                    const uint32_t *__restrict__ point_list) {
   // Each wave (one 8x8 quadrant) walks the tile list on its own: private 64-record staging area, no
   // workgroup barrier anywhere, so a quadrant never waits for a slower neighbour.  The four waves of a
   // tile read the same records; the repeats are served by L1/L2.
@@ -77,11 +78,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
   if (__builtin_amdgcn_ballot_w64(!done) != 0ull && range.x < range.y) {
     // the next chunk's records are requested from HBM/L2 before the current chunk is composited
     float4 q0, q1, q2;
+    const bool rec16 = counters[7] != 0u;  // fp16-storage records (gsaj_common.h)
     auto fetch = [&](uint32_t base) {
-      if (base + (uint32_t)lane < range.y) {
-        const float4 *src = records + (size_t)(base + lane) * REC_F4;
-        q0 = src[0], q1 = src[1], q2 = src[2];
-      }
+      if (base + (uint32_t)lane < range.y) gsaj_load_record(records, point_list, (size_t)(base + lane), rec16, q0, q1, q2);
     };
     fetch(range.x);
     for (uint32_t base = range.x; base < range.y; base += FWD_CHUNK) {
@@ -174,7 +173,7 @@ int launch_render_forward(int W, int H, int grid_x, int grid_y, const float *bg,
   {
     GsajProfScope ps(ST_RENDER_FWD, s);
     hipLaunchKernelGGL(k_render_fwd, dim3(grid_x * grid_y), dim3(256), 0, s, W, H, grid_x, im.ranges, b.records, bg,
-                     im.final_T, im.n_contrib, out_color, out_depth, out_opacity, n_touched, im.counters, im.finish_list);
+                     im.final_T, im.n_contrib, out_color, out_depth, out_opacity, n_touched, im.counters, im.finish_list, b.point_list);
   }
   GSAJ_HIP_CHECK(hipGetLastError());
   return GSAJ_OK;

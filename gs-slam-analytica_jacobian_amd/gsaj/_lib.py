@@ -37,6 +37,7 @@ SIGNATURES = {
                                             P, P, c_int, c_int, P]),
     "gsaj_rasterize_backward": (c_int, [c_int, c_int, c_int, c_int, P, c_int, c_int, P, P, P, P, c_float, P, P, P, P, P, P,
                                         c_float, c_float, P, P, P, P, P, P] + [P] * 12 + [P]),
+    "gsaj_set_record_format": (c_int, [c_int]),
     "gsaj_mark_visible": (c_int, [c_int, P, P, P, P, P]),
     "gsaj_debug_export": (c_int, [c_int] * 4 + [P] * 3 + [P] * 11 + [P]),
     "gsaj_profile_begin": (c_int, [c_int]),

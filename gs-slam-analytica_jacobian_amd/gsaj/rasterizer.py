@@ -234,6 +234,12 @@ class profile_stages:
         return False
 
 
+def set_record_format(bits):
+    """16: the sorted instance records store conic / opacity / colour as halves (32-byte records; positions, depth and all
+    accumulation stay fp32).  32: the default fp32 records.  Process-wide, applies to forwards launched afterwards."""
+    _lib.check(_lib.load().gsaj_set_record_format(int(bits)), "gsaj_set_record_format")
+
+
 class FrameContext:
     """Pre-allocated outputs and workspaces for repeated forward+backward passes over one scene
     size (the tracking / mapping inner loop): no allocation and two C-ABI calls per step.

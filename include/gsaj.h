@@ -131,6 +131,13 @@ int gsaj_forward_preprocess_cap(int P, int D, int M, int W, int H,
                                 float tanfovx, float tanfovy, int prefiltered, int *radii, int *n_touched,
                                 void *geom_ws, void *image_ws, int capacity, int tile_list_capacity, void *stream);
 
+/* Storage format of the sorted instance records written by the forwards launched from now on (process-wide):
+ * 32 (default): 48-byte fp32 records.  16: 32-byte records with conic, opacity and colour rounded to half once
+ * (positions, depth, every accumulation and every gradient stay fp32) -- BASELINE config 5, "fp16 splat with
+ * fp32 Jacobian accumulation"; integer outputs (radii, lists, ranges) are unchanged, images / gradients move by
+ * ~1e-3 relative.  The backward reads the format the matching forward used from the image workspace. */
+int gsaj_set_record_format(int bits);
+
 /* ---- backward ------------------------------------------------------------------------ */
 /* dL_dpix [3,H,W], dL_dpix_depth [1,H,W] -> dL_dmean2D [P,3] (NDC-scaled, z unused),
  * dL_dconic [P,2,2] (slots 0,1,3), dL_dopacity [P], dL_dcolor [P,3], dL_ddepth [P],
