@@ -3,6 +3,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
+#include <mutex>
+
 #include "gsaj_common.h"
 
 static thread_local char g_err[512] = "";
@@ -21,26 +24,37 @@ static uint32_t higher_msb(uint32_t n) {  // number of bits needed for tile ids 
 }
 
 // ---- event-based per-stage profiler ------------------------------------------------------------
+// Shared by every thread / stream of the process: the record table is guarded by a mutex, a record is claimed with an
+// atomic index, and the record a launch scope has open is thread-local (a scope opens and closes on one thread), so
+// concurrent launches from a tracking and a mapping thread each time their own kernels.
 struct ProfRec { int stage; hipEvent_t a, b; };
+static std::mutex g_prof_mu;
 static ProfRec *g_prof = nullptr;
-static int g_prof_cap = 0, g_prof_n = 0, g_prof_open = -1;
+static std::atomic<bool> g_prof_on{false};
+static int g_prof_cap = 0;
+static std::atomic<int> g_prof_n{0};
+static thread_local int t_prof_open = -1;
 
 void gsaj_prof_mark(int stage, int is_stop, hipStream_t s) {
+  if (!g_prof_on.load(std::memory_order_acquire)) return;  // the common case: one relaxed-cost load, no lock
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   if (!g_prof) return;
   if (!is_stop) {
-    if (g_prof_n >= g_prof_cap) { g_prof_open = -1; return; }
-    g_prof_open = g_prof_n++;
-    g_prof[g_prof_open].stage = stage;
-    (void)hipEventRecord(g_prof[g_prof_open].a, s);
-  } else if (g_prof_open >= 0) {
-    (void)hipEventRecord(g_prof[g_prof_open].b, s);
-    g_prof_open = -1;
+    const int i = g_prof_n.fetch_add(1);
+    if (i >= g_prof_cap) { g_prof_n.store(g_prof_cap); t_prof_open = -1; return; }
+    t_prof_open = i;
+    g_prof[i].stage = stage;
+    (void)hipEventRecord(g_prof[i].a, s);
+  } else if (t_prof_open >= 0 && t_prof_open < g_prof_cap) {
+    (void)hipEventRecord(g_prof[t_prof_open].b, s);
+    t_prof_open = -1;
   }
 }
 
 extern "C" {
 
 int gsaj_profile_begin(int max_records) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   if (g_prof || max_records <= 0) {
     gsaj_set_error("gsaj_profile_begin: already active or bad size");
     return GSAJ_ERR_INVALID_ARGUMENT;
@@ -51,19 +65,26 @@ int gsaj_profile_begin(int max_records) {
     GSAJ_HIP_CHECK(hipEventCreate(&g_prof[i].b));
   }
   g_prof_cap = max_records;
-  g_prof_n = 0;
-  g_prof_open = -1;
+  g_prof_n.store(0);
+  g_prof_on.store(true, std::memory_order_release);
   return GSAJ_OK;
 }
 
 int gsaj_profile_end(float *stage_ms, int *stage_launches) {
-  if (!g_prof || !stage_ms || !stage_launches) {
+  if (!stage_ms || !stage_launches) {
+    gsaj_set_error("gsaj_profile_end: null output");
+    return GSAJ_ERR_INVALID_ARGUMENT;
+  }
+  g_prof_on.store(false, std::memory_order_release);  // no new records; launches in flight finish under the lock
+  GSAJ_HIP_CHECK(hipDeviceSynchronize());
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (!g_prof) {
     gsaj_set_error("gsaj_profile_end: not active");
     return GSAJ_ERR_INVALID_ARGUMENT;
   }
-  GSAJ_HIP_CHECK(hipDeviceSynchronize());
   for (int i = 0; i < ST_COUNT; i++) { stage_ms[i] = 0.f; stage_launches[i] = 0; }
-  for (int i = 0; i < g_prof_n; i++) {
+  const int nrec = g_prof_n.load() < g_prof_cap ? g_prof_n.load() : g_prof_cap;
+  for (int i = 0; i < nrec; i++) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, g_prof[i].a, g_prof[i].b) == hipSuccess) {
       stage_ms[g_prof[i].stage] += ms;
@@ -73,7 +94,8 @@ int gsaj_profile_end(float *stage_ms, int *stage_launches) {
   for (int i = 0; i < g_prof_cap; i++) { (void)hipEventDestroy(g_prof[i].a); (void)hipEventDestroy(g_prof[i].b); }
   delete[] g_prof;
   g_prof = nullptr;
-  g_prof_cap = g_prof_n = 0;
+  g_prof_cap = 0;
+  g_prof_n.store(0);
   return GSAJ_OK;
 }
 
@@ -185,21 +207,10 @@ int gsaj_forward_aborted_count(int W, int H, const void *image_ws, void *stream,
   return GSAJ_OK;
 }
 
-static int g_rec16 = 0;  // process-wide: record storage of the frames launched from now on (gsaj_set_record_format)
-
-int gsaj_set_record_format(int bits) {
-  if (bits != 16 && bits != 32) {
-    gsaj_set_error("gsaj_set_record_format: 16 or 32, got %d", bits);
-    return GSAJ_ERR_INVALID_ARGUMENT;
-  }
-  g_rec16 = bits == 16;
-  return GSAJ_OK;
-}
-
 int gsaj_forward_render(int P, int R, int max_tile_list, int W, int H, const float *bg, const float *colors_precomp,
                         const int *radii,
                         void *geom_ws, void *binning_ws, size_t binning_ws_bytes, void *image_ws, float *out_color,
-                        float *out_depth, float *out_opacity, int *n_touched, void *stream) {
+                        float *out_depth, float *out_opacity, int *n_touched, int flags, void *stream) {
   if (P <= 0 || R < 0 || W <= 0 || H <= 0 || !bg || !geom_ws || !binning_ws || !image_ws || !out_color || !out_depth ||
       !out_opacity || !n_touched) {
     gsaj_set_error("gsaj_forward_render: invalid argument");
@@ -223,7 +234,7 @@ int gsaj_forward_render(int P, int R, int max_tile_list, int W, int H, const flo
   int rc;
   if (max_tile_list >= 0 && max_tile_list <= SORT_CAP) {
     // fast path: per-tile lists sorted in LDS
-    if ((rc = launch_tile_binning(P, R, max_tile_list, g_rec16, gx, gy, rad, features, g, b, im, s)) != GSAJ_OK) return rc;
+    if ((rc = launch_tile_binning(P, R, max_tile_list, (flags & GSAJ_FWD_RECORDS_FP16) ? 1 : 0, gx, gy, rad, features, g, b, im, s)) != GSAJ_OK) return rc;
   } else {
     // a tile list exceeds the LDS sort capacity (or the caller forces it with max_tile_list < 0):
     // global radix sort of (tile << 32 | depth) keys, as the reference does
@@ -240,7 +251,7 @@ int gsaj_rasterize_forward(int P, int D, int M, const float *bg, int W, int H, c
                            const float *viewmatrix, const float *projmatrix, const float *campos, float tanfovx,
                            float tanfovy, int prefiltered, float *out_color, float *out_depth, float *out_opacity,
                            int *radii, int *n_touched, void *geom_ws, void *binning_ws, size_t binning_ws_bytes,
-                           void *image_ws, int *num_rendered_out, void *stream) {
+                           void *image_ws, int *num_rendered_out, int flags, void *stream) {
   int rc = gsaj_forward_preprocess(P, D, M, W, H, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
                                    rotations, cov3D_precomp, viewmatrix, projmatrix, campos, tanfovx, tanfovy,
                                    prefiltered, radii, n_touched, geom_ws, image_ws, stream);
@@ -250,7 +261,7 @@ int gsaj_rasterize_forward(int P, int D, int M, const float *bg, int W, int H, c
   if (num_rendered_out) *num_rendered_out = R;
   if (rc != GSAJ_OK) return rc;
   rc = gsaj_forward_render(P, R, max_tile, W, H, bg, colors_precomp, radii, geom_ws, binning_ws, binning_ws_bytes, image_ws,
-                           out_color, out_depth, out_opacity, n_touched, stream);
+                           out_color, out_depth, out_opacity, n_touched, flags, stream);
   return rc == GSAJ_OK ? R : rc;
 }
 
@@ -260,7 +271,7 @@ int gsaj_rasterize_forward_async(int P, int D, int M, const float *bg, int W, in
                                  const float *viewmatrix, const float *projmatrix, const float *campos, float tanfovx,
                                  float tanfovy, int prefiltered, float *out_color, float *out_depth, float *out_opacity,
                                  int *radii, int *n_touched, void *geom_ws, void *binning_ws, size_t binning_ws_bytes,
-                                 int capacity, int tile_list_capacity, void *image_ws, void *stream) {
+                                 int capacity, int tile_list_capacity, void *image_ws, int flags, void *stream) {
   if (capacity <= 0 || !binning_ws || !bg || !out_color || !out_depth || !out_opacity || !n_touched) {
     gsaj_set_error("gsaj_rasterize_forward_async: invalid argument");
     return GSAJ_ERR_INVALID_ARGUMENT;
@@ -287,7 +298,7 @@ int gsaj_rasterize_forward_async(int P, int D, int M, const float *bg, int W, in
   const int *rad = radii ? radii : g.internal_radii;
   const float *features = colors_precomp ? colors_precomp : g.rgb;
   const int sort_cap = (tile_list_capacity > 0 && tile_list_capacity < SORT_CAP) ? tile_list_capacity : SORT_CAP;
-  if ((rc = launch_tile_binning(P, capacity, sort_cap, g_rec16, gx, gy, rad, features, g, b, im, s)) != GSAJ_OK) return rc;
+  if ((rc = launch_tile_binning(P, capacity, sort_cap, (flags & GSAJ_FWD_RECORDS_FP16) ? 1 : 0, gx, gy, rad, features, g, b, im, s)) != GSAJ_OK) return rc;
   return launch_render_forward(W, H, gx, gy, bg, b, im, out_color, out_depth, out_opacity, n_touched, s);
 }
 

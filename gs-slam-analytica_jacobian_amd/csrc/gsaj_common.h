@@ -219,6 +219,20 @@ __device__ __forceinline__ void tile_rect(float px, float py, int r, int gx, int
   x1 = min(gx, max(0, (int)((px + (float)r + (float)(TILE - 1)) / (float)TILE)));
   y1 = min(gy, max(0, (int)((py + (float)r + (float)(TILE - 1)) / (float)TILE)));
 }
+// ---- the compositors' alpha, ONE definition for the forward and the reverse pass ----------------------------------
+// power = -(a dx^2 + c dy^2)/2 - b dx dy is evaluated as log2(e) * power from the pre-scaled conic
+// k = (-log2(e)/2 a, -log2(e) b, -log2(e)/2 c) with explicit fused operations, so that both passes get the SAME bits for
+// every (pixel, entry) and therefore take the same power <= 0 / alpha >= 1/255 decisions (the reference evaluates the
+// identical expression in forward.cu:470-486 and backward.cu:757-766).  G = exp(power) = v_exp_f32(p2).
+#define GSAJ_LOG2E 1.4426950408889634f
+__device__ __forceinline__ float3 gsaj_prescale_conic(float a, float b, float c) {
+  return make_float3((-0.5f * GSAJ_LOG2E) * a, -GSAJ_LOG2E * b, (-0.5f * GSAJ_LOG2E) * c);
+}
+__device__ __forceinline__ float gsaj_power2(float dx, float dy, float kx, float ky, float kz) {
+  const float t = ky * dy;
+  const float u = kz * dy;
+  return __builtin_fmaf(dx, __builtin_fmaf(kx, dx, t), u * dy);
+}
 __device__ __forceinline__ float3 cross3(float3 a, float3 b) {
   return make_float3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }

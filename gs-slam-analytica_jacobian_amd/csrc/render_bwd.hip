@@ -206,10 +206,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
             n2 = rec[jj * REC_F4 + 2];
           }
           const float dx = r0.x - pxf, dy = r0.y - pyf;
-          const float power = -0.5f * (r1.x * dx * dx + r1.z * dy * dy) - r1.y * dx * dy;
-          const float G0 = __expf(power);
+          // the forward's own expression (gsaj_common.h): both passes decide power <= 0 / alpha >= 1/255 on identical bits
+          const float3 kc = gsaj_prescale_conic(r1.x, r1.y, r1.z);
+          const float p2 = gsaj_power2(dx, dy, kc.x, kc.y, kc.z);
+          const float G0 = __builtin_amdgcn_exp2f(p2);
           const float alpha0 = fminf(0.99f, r1.w * G0);
-          const bool valid = idx < last && power <= 0.0f && alpha0 >= (1.0f / 255.0f);
+          const bool valid = idx < last && p2 <= 0.0f && alpha0 >= (1.0f / 255.0f);
           if (__builtin_amdgcn_ballot_w64(valid) != 0ull) {
             // a lane that skips this entry runs the same arithmetic with alpha = G = 0: T and accum_rec
             // come out unchanged and (w, u) = 0

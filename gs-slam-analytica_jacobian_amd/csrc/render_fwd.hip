@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
   // A pixel that skips the entry runs the same arithmetic with alpha = 0: T, C, D come out unchanged.
   auto composite = [&](const float4 g, const float4 k, const float4 c, float &test_T) -> bool {
     const float dx = g.x - pxf, dy = g.y - pyf;
-    const float p2 = dx * (k.x * dx + k.y * dy) + (k.z * dy) * dy;
+    const float p2 = gsaj_power2(dx, dy, k.x, k.y, k.z);
     const float alpha0 = fminf(0.99f, k.w * __builtin_amdgcn_exp2f(p2));
     bool ok = !done && p2 <= 0.0f && alpha0 >= (1.0f / 255.0f);
     test_T = T - alpha0 * T;
@@ -94,9 +94,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
       __builtin_amdgcn_wave_barrier();
       if (rel) {
         const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(todo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)todo, 0u));
-        const float L2E = 1.4426950408889634f;
+        const float3 k = gsaj_prescale_conic(q1.x, q1.y, q1.z);
         rec[slot * REC_F4 + 0] = q0;
-        rec[slot * REC_F4 + 1] = make_float4((-0.5f * L2E) * q1.x, -L2E * q1.y, (-0.5f * L2E) * q1.z, q1.w);
+        rec[slot * REC_F4 + 1] = make_float4(k.x, k.y, k.z, q1.w);
         rec[slot * REC_F4 + 2] = make_float4(q2.x, q2.y, q2.z, __uint_as_float(base - range.x + (uint32_t)lane + 1u));
       }
       if (lane < FWD_PAD * REC_F4) rec[nrel * REC_F4 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);  // inert sentinels (opacity 0)

@@ -26,18 +26,17 @@ SIGNATURES = {
     "gsaj_binning_workspace_bytes": (c_size_t, [c_int]),
     "gsaj_forward_preprocess": (c_int, [c_int] * 5 + [P, P, P, P, P, c_float, P, P, P, P, P, c_float, c_float, c_int, P, P, P, P, P]),
     "gsaj_forward_num_rendered": (c_int, [c_int, c_int, P, P, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
-    "gsaj_forward_render": (c_int, [c_int] * 5 + [P, P, P, P, P, c_size_t, P, P, P, P, P, P]),
+    "gsaj_forward_render": (c_int, [c_int] * 5 + [P, P, P, P, P, c_size_t, P, P, P, P, P, c_int, P]),
     "gsaj_rasterize_forward": (c_int, [c_int, c_int, c_int, P, c_int, c_int, P, P, P, P, P, c_float, P, P, P, P, P,
                                        c_float, c_float, c_int, P, P, P, P, P, P, P, c_size_t, P,
-                                       ctypes.POINTER(c_int), P]),
+                                       ctypes.POINTER(c_int), c_int, P]),
     "gsaj_rasterize_forward_async": (c_int, [c_int, c_int, c_int, P, c_int, c_int, P, P, P, P, P, c_float, P, P, P, P, P,
-                                             c_float, c_float, c_int, P, P, P, P, P, P, P, c_size_t, c_int, c_int, P, P]),
+                                             c_float, c_float, c_int, P, P, P, P, P, P, P, c_size_t, c_int, c_int, P, c_int, P]),
     "gsaj_forward_aborted_count": (c_int, [c_int, c_int, P, P, ctypes.POINTER(c_int)]),
     "gsaj_forward_preprocess_cap": (c_int, [c_int] * 5 + [P, P, P, P, P, c_float, P, P, P, P, P, c_float, c_float, c_int, P, P,
                                             P, P, c_int, c_int, P]),
     "gsaj_rasterize_backward": (c_int, [c_int, c_int, c_int, c_int, P, c_int, c_int, P, P, P, P, c_float, P, P, P, P, P, P,
                                         c_float, c_float, P, P, P, P, P, P] + [P] * 12 + [P]),
-    "gsaj_set_record_format": (c_int, [c_int]),
     "gsaj_mark_visible": (c_int, [c_int, P, P, P, P, P]),
     "gsaj_debug_export": (c_int, [c_int] * 4 + [P] * 3 + [P] * 11 + [P]),
     "gsaj_profile_begin": (c_int, [c_int]),

@@ -44,9 +44,10 @@ def _require_cuda(t, what):
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, projmatrix_raw, tan_fovx, tan_fovy, image_height, image_width, sh,
-                        degree, campos, prefiltered, debug):
+                        degree, campos, prefiltered, debug, record_bits=32):
     """-> (num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer, depth, opacity, n_touched)
-    (RasterizeGaussiansCUDA, rasterize_points.cu:36-130)."""
+    (RasterizeGaussiansCUDA, rasterize_points.cu:36-130).  record_bits=16: this frame's sorted instance records store
+    conic / opacity / colour as halves (GSAJ_FWD_RECORDS_FP16; a per-call flag, nothing process-wide)."""
     lib = _lib.load()
     if means3D.ndim != 2 or means3D.shape[1] != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
@@ -95,7 +96,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         _lib.check(lib.gsaj_forward_render(
             P, R, -1 if FORCE_GLOBAL_SORT else mt.value, W, H, _ptr(background), _ptr(colors), radii.data_ptr(), geom.data_ptr(), binning.data_ptr(), nbytes,
             img.data_ptr(), out_color.data_ptr(), out_depth.data_ptr(), out_opacity.data_ptr(), n_touched.data_ptr(),
-            st), "gsaj_forward_render")
+            _fwd_flags(record_bits), st), "gsaj_forward_render")
         if debug:
             torch.cuda.synchronize(dev)
     return R, out_color, radii, geom, binning, img, out_depth, out_opacity, n_touched
@@ -234,10 +235,15 @@ class profile_stages:
         return False
 
 
-def set_record_format(bits):
+FWD_RECORDS_FP16 = 1  # GSAJ_FWD_RECORDS_FP16 (include/gsaj.h)
+
+
+def _fwd_flags(record_bits):
     """16: the sorted instance records store conic / opacity / colour as halves (32-byte records; positions, depth and all
-    accumulation stay fp32).  32: the default fp32 records.  Process-wide, applies to forwards launched afterwards."""
-    _lib.check(_lib.load().gsaj_set_record_format(int(bits)), "gsaj_set_record_format")
+    accumulation stay fp32).  32: the default fp32 records."""
+    if record_bits not in (16, 32):
+        raise ValueError("record_bits must be 16 or 32, got %r" % (record_bits,))
+    return FWD_RECORDS_FP16 if record_bits == 16 else 0
 
 
 class FrameContext:
@@ -246,8 +252,9 @@ class FrameContext:
     The binning workspace grows geometrically when a frame produces more instances."""
 
     def __init__(self, P, W, H, M, device, has_scales=True, per_gaussian_tau=False, grad_slots=1, n_keyframes=0,
-                 keyframe=0):
+                 keyframe=0, record_bits=32):
         lib = _lib.load()
+        self.flags = _fwd_flags(record_bits)  # per context (= per view), handed to every forward call
         self.lib, self.P, self.W, self.H, self.M, self.dev = lib, P, W, H, M, torch.device(device)
         f = dict(device=self.dev, dtype=_F32)
         byte = dict(device=self.dev, dtype=torch.uint8)
@@ -316,7 +323,7 @@ class FrameContext:
                 _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tanfovx), float(tanfovy), 0,
                 self.color.data_ptr(), self.depth.data_ptr(), self.opacity.data_ptr(), self.radii.data_ptr(),
                 self.n_touched.data_ptr(), self.geom.data_ptr(), self.binning.data_ptr(), self.binning.numel(),
-                self.capacity, self.tile_list_capacity, self.img.data_ptr(), st), "gsaj_rasterize_forward_async")
+                self.capacity, self.tile_list_capacity, self.img.data_ptr(), self.flags, st), "gsaj_rasterize_forward_async")
             self.R = self.capacity  # what the backward must be given (arena carving)
             return self.R
         _lib.check(lib.gsaj_forward_preprocess(
@@ -336,7 +343,7 @@ class FrameContext:
         _lib.check(lib.gsaj_forward_render(
             self.P, self.R, -1 if FORCE_GLOBAL_SORT else self.max_tile_list, self.W, self.H, _ptr(bg), _ptr(colors_precomp), self.radii.data_ptr(), self.geom.data_ptr(),
             self.binning.data_ptr(), self.binning.numel(), self.img.data_ptr(), self.color.data_ptr(),
-            self.depth.data_ptr(), self.opacity.data_ptr(), self.n_touched.data_ptr(), st), "gsaj_forward_render")
+            self.depth.data_ptr(), self.opacity.data_ptr(), self.n_touched.data_ptr(), self.flags, st), "gsaj_forward_render")
         return self.R
 
     def backward(self, bg, means3D, viewmatrix, projmatrix, projmatrix_raw, campos, tanfovx, tanfovy, dL_dcolor, dL_ddepth,

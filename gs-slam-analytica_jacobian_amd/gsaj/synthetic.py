@@ -135,12 +135,26 @@ def config_scene(name):
     elif name == "cfg3":  # Replica calibration, 300k, SH0
         cam = make_camera(orthonormalize(W2C_GT @ T_NOISE), W=1200, H=680, fx=600.0, fy=600.0, cx=599.5, cy=339.5)
         sc = make_scene(300_000, 300000, cam, z_range=(1.0, 5.0), sh_coeffs=1)
+    elif name == "cfg4":  # TUM fr1_desk calibration (configs/rgbd/tum/fr1_desk.yaml), 100k Gaussians; the 8 keyframes: config_window
+        cam = make_camera(orthonormalize(W2C_GT @ T_NOISE), **TUM_FR1)
+        sc = make_scene(100_000, 100000, cam, z_range=(1.0, 6.0), margin=0.25)
     elif name == "cfg5":  # 1M Gaussians, 1280x720
         cam = make_camera(orthonormalize(W2C_GT @ T_NOISE), W=1280, H=720, fx=870.0, fy=870.0, cx=639.5, cy=359.5)
         sc = make_scene(1_000_000, 1000000, cam, z_range=(1.0, 8.0), sh_coeffs=1)
     else:
         raise KeyError(name)
     return cam, sc
+
+
+TUM_FR1 = dict(W=640, H=480, fx=517.306408, fy=516.469215, cx=318.643040, cy=255.313989)
+
+
+def config_window(name="cfg4", n=8):
+    """Mapping window of BASELINE config 4 (synthetic stand-in): n keyframe cameras (window_size 8,
+    configs/rgbd/tum/base_config.yaml:36) on a 0.5 m arc over ONE shared Gaussian map -> (cameras, scene)."""
+    cam0, sc = config_scene(name)
+    kw = {k: cam0[k] for k in ("W", "H", "fx", "fy", "cx", "cy")}
+    return keyframe_cameras(n, **kw), sc
 
 
 def keyframe_cameras(n, radius=0.5, **kw):

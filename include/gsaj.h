@@ -61,6 +61,15 @@ size_t gsaj_geom_workspace_bytes(int P);
 size_t gsaj_image_workspace_bytes(int W, int H);
 size_t gsaj_binning_workspace_bytes(int R);
 
+/* ---- per-call flags of the forward entry points (the library keeps NO process-wide mode: two threads may render
+ * frames of different formats on different streams at the same time) ---------------------------------------------
+ * GSAJ_FWD_RECORDS_FP16: the sorted instance records of THIS frame are 32-byte records with conic, opacity and colour
+ * rounded to half once (positions, depth, every accumulation and every gradient stay fp32) -- BASELINE config 5,
+ * "fp16 splat with fp32 Jacobian accumulation"; integer outputs (radii, lists, ranges) are unchanged, images /
+ * gradients move by ~1e-3 relative.  Default: 48-byte fp32 records.  The format is latched in the frame's image
+ * workspace, where the matching backward reads it. */
+#define GSAJ_FWD_RECORDS_FP16 1
+
 /* ---- forward, two-phase form --------------------------------------------------------- */
 /* Phase A: per-Gaussian projection (cov3D, EWA cov2D + 0.3, conic, radius, tile rect,
  * SH -> RGB) and the prefix sum of tiles touched.  Writes radii[P] (int32, may be NULL). */
@@ -84,7 +93,8 @@ int gsaj_forward_render(int P, int R, int max_tile_list /* from phase A; < 0 for
                         const float *bg /*dev [3]*/,
                         const float *colors_precomp /*dev [P,3] or NULL*/, const int *radii /*dev [P] or NULL*/,
                         void *geom_ws, void *binning_ws, size_t binning_ws_bytes, void *image_ws,
-                        float *out_color, float *out_depth, float *out_opacity, int *n_touched, void *stream);
+                        float *out_color, float *out_depth, float *out_opacity, int *n_touched,
+                        int flags /* GSAJ_FWD_*: takes the place of the reference's `bool debug` */, void *stream);
 
 /* ---- forward, one call (phase A, sync, phase B).  The caller supplies a binning
  * workspace of any capacity; if it is too small the call fails with
@@ -97,7 +107,7 @@ int gsaj_rasterize_forward(int P, int D, int M, const float *bg, int W, int H,
                            float tanfovx, float tanfovy, int prefiltered,
                            float *out_color, float *out_depth, float *out_opacity, int *radii, int *n_touched,
                            void *geom_ws, void *binning_ws, size_t binning_ws_bytes, void *image_ws,
-                           int *num_rendered_out /*host, may be NULL*/, void *stream);
+                           int *num_rendered_out /*host, may be NULL*/, int flags /* GSAJ_FWD_* */, void *stream);
 
 /* ---- forward without any host synchronisation (tracking / mapping inner loops) -----------------
  * The caller provides a binning workspace sized for `capacity` instances
@@ -118,7 +128,7 @@ int gsaj_rasterize_forward_async(int P, int D, int M, const float *bg, int W, in
                                  float tanfovx, float tanfovy, int prefiltered,
                                  float *out_color, float *out_depth, float *out_opacity, int *radii, int *n_touched,
                                  void *geom_ws, void *binning_ws, size_t binning_ws_bytes, int capacity, int tile_list_capacity,
-                                 void *image_ws, void *stream);
+                                 void *image_ws, int flags /* GSAJ_FWD_* */, void *stream);
 /* Blocking: number of async forwards aborted on the device since the image workspace was zeroed by
  * the caller (the caller zero-fills the image workspace once, when it allocates it). */
 int gsaj_forward_aborted_count(int W, int H, const void *image_ws, void *stream, int *count /*host*/);
@@ -130,13 +140,6 @@ int gsaj_forward_preprocess_cap(int P, int D, int M, int W, int H,
                                 const float *viewmatrix, const float *projmatrix, const float *campos,
                                 float tanfovx, float tanfovy, int prefiltered, int *radii, int *n_touched,
                                 void *geom_ws, void *image_ws, int capacity, int tile_list_capacity, void *stream);
-
-/* Storage format of the sorted instance records written by the forwards launched from now on (process-wide):
- * 32 (default): 48-byte fp32 records.  16: 32-byte records with conic, opacity and colour rounded to half once
- * (positions, depth, every accumulation and every gradient stay fp32) -- BASELINE config 5, "fp16 splat with
- * fp32 Jacobian accumulation"; integer outputs (radii, lists, ranges) are unchanged, images / gradients move by
- * ~1e-3 relative.  The backward reads the format the matching forward used from the image workspace. */
-int gsaj_set_record_format(int bits);
 
 /* ---- backward ------------------------------------------------------------------------ */
 /* dL_dpix [3,H,W], dL_dpix_depth [1,H,W] -> dL_dmean2D [P,3] (NDC-scaled, z unused),

@@ -1,7 +1,7 @@
 /*
  * gsaj_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE ONLY, never a product path).
  *
- * A plain-C, single-threaded, fp32 restatement of the *rasteriser semantics* of the
+ * A plain-C, fp32 restatement of the *rasteriser semantics* of the
  * reference's Gaussian-splat hot path: per-Gaussian projection, 16x16 tile binning,
  * front-to-back alpha compositing of colour + depth, and the closed-form backward that
  * yields dL/dmean2D, dL/dconic, per-Gaussian parameter gradients and the SE(3) pose
@@ -32,14 +32,35 @@
  * Against CUDA outputs themselves: parity unpinned (no runnable reference, inputs of the
  * recorded grad_tau prints are missing blobs).
  *
- * Build: gcc -O2 -ffp-contract=off -fPIC -shared (see oracle/Makefile).
+ * Threads: the per-Gaussian loops and the per-tile loops are OpenMP-parallel (tiles are independent); the number
+ * of threads is set with gsaj_oracle_set_threads (default 1).  Results do not depend on the thread count: every
+ * floating-point sum has a fixed order (per-pixel sums inside one tile by one thread; a Gaussian's per-tile partials
+ * are added in sorted-instance order by a serial pass), integer counters use atomic increments.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fopenmp -fPIC -shared (see oracle/Makefile).
  */
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define TILE 16
+
+static int g_threads = 1;
+/* Number of OpenMP threads of the parallel loops (test / benchmark harness knob; 0 = all cores). Returns the value in use. */
+int gsaj_oracle_set_threads(int n) {
+#ifdef _OPENMP
+  if (n <= 0) n = omp_get_num_procs();
+  g_threads = n;
+#else
+  (void)n;
+  g_threads = 1;
+#endif
+  return g_threads;
+}
 
 static const float SH_C0 = 0.28209479177387814f;
 static const float SH_C1 = 0.4886025119029199f;
@@ -49,19 +70,32 @@ static const float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570
                                0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
                                -0.5900435899266435f};
 
-/* viewmatrix / projmatrix arrive as 16 floats = column-major W2C / P*W2C
- * (reference: auxiliary.h:58-77). */
-static void xform4x3(const float *m, const float *p, float *o) {
-  o[0] = m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12];
-  o[1] = m[1] * p[0] + m[5] * p[1] + m[9] * p[2] + m[13];
-  o[2] = m[2] * p[0] + m[6] * p[1] + m[10] * p[2] + m[14];
-}
-static void xform4x4(const float *m, const float *p, float *o) {
-  o[0] = m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12];
-  o[1] = m[1] * p[0] + m[5] * p[1] + m[9] * p[2] + m[13];
-  o[2] = m[2] * p[0] + m[6] * p[1] + m[10] * p[2] + m[14];
-  o[3] = m[3] * p[0] + m[7] * p[1] + m[11] * p[2] + m[15];
-}
+/* The small-matrix helpers, the shared projection step (cov2d_eval) and the whole per-Gaussian backward live in
+ * chain_body.inc, instantiated twice: in fp32 (the restatement of the reference's arithmetic; un-suffixed names) and in
+ * fp64 (suffix _f64; same operations, used by the parity tests as the "truth" that tells rounding noise of ANY fp32
+ * evaluation from a wrong formula). */
+#define REAL float
+#define RN(x) x
+#define R_SQRT sqrtf
+#define R_FMIN fminf
+#define R_FMAX fmaxf
+#include "chain_body.inc"
+#undef REAL
+#undef RN
+#undef R_SQRT
+#undef R_FMIN
+#undef R_FMAX
+#define REAL double
+#define RN(x) x##_f64
+#define R_SQRT sqrt
+#define R_FMIN fmin
+#define R_FMAX fmax
+#include "chain_body.inc"
+#undef REAL
+#undef RN
+#undef R_SQRT
+#undef R_FMIN
+#undef R_FMAX
 
 /* pixel = ((ndc + 1) * S - 1) / 2, evaluated in double like the reference's
  * un-suffixed constants (auxiliary.h:41-44). */
@@ -78,14 +112,6 @@ static void tile_rect(float px, float py, int r, int gx, int gy, int *x0, int *y
   *y1 = imin(gy, imax(0, (int)((py + (float)r + (float)(TILE - 1)) / (float)TILE)));
 }
 
-/* Rotation matrix (row-major) of an un-normalised quaternion (r,x,y,z); forward.cu:129-142. */
-static void quat_to_R(const float *q, float R[3][3]) {
-  float r = q[0], x = q[1], y = q[2], z = q[3];
-  R[0][0] = 1.f - 2.f * (y * y + z * z); R[0][1] = 2.f * (x * y - r * z);       R[0][2] = 2.f * (x * z + r * y);
-  R[1][0] = 2.f * (x * y + r * z);       R[1][1] = 1.f - 2.f * (x * x + z * z); R[1][2] = 2.f * (y * z - r * x);
-  R[2][0] = 2.f * (x * z - r * y);       R[2][1] = 2.f * (y * z + r * x);       R[2][2] = 1.f - 2.f * (x * x + y * y);
-}
-
 /* Sigma = R S^2 R^T, upper triangle (xx,xy,xz,yy,yz,zz); forward.cu:120-154.
  * A[i][j] = s_i * R[j][i]  (A = S R^T), Sigma[r][c] = sum_k A[k][r] A[k][c]. */
 static void cov3d_from_scale_rot(const float *scale, float mod, const float *rot, float *c6) {
@@ -97,45 +123,6 @@ static void cov3d_from_scale_rot(const float *scale, float mod, const float *rot
   for (int r = 0; r < 3; r++)
     for (int c = 0; c < 3; c++) S[r][c] = A[0][r] * A[0][c] + A[1][r] * A[1][c] + A[2][r] * A[2][c];
   c6[0] = S[0][0]; c6[1] = S[0][1]; c6[2] = S[0][2]; c6[3] = S[1][1]; c6[4] = S[1][2]; c6[5] = S[2][2];
-}
-
-/* Shared by forward and backward: clamped camera-space point t, the 2x3 matrix
- * M = J * Rcw (rows of the projective Jacobian times the rotation block), and the
- * dilated 2D covariance (a,b,c).  forward.cu:76-115 / backward.cu:176-205. */
-typedef struct {
-  float t[3], txtz, tytz, limx, limy;
-  float J00, J02, J11, J12;
-  float Rcw[3][3]; /* row-major rotation block of W2C */
-  float M[2][3];
-  float V[3][3];
-  float a, b, c;
-} Cov2D;
-
-static void cov2d_eval(const float *mean, float fx, float fy, float tanx, float tany, const float *c6,
-                       const float *vm, Cov2D *o) {
-  xform4x3(vm, mean, o->t);
-  o->limx = 1.3f * tanx; o->limy = 1.3f * tany;
-  o->txtz = o->t[0] / o->t[2]; o->tytz = o->t[1] / o->t[2];
-  o->t[0] = fminf(o->limx, fmaxf(-o->limx, o->txtz)) * o->t[2];
-  o->t[1] = fminf(o->limy, fmaxf(-o->limy, o->tytz)) * o->t[2];
-  float tz = o->t[2];
-  o->J00 = fx / tz; o->J02 = -(fx * o->t[0]) / (tz * tz);
-  o->J11 = fy / tz; o->J12 = -(fy * o->t[1]) / (tz * tz);
-  for (int r = 0; r < 3; r++)
-    for (int c = 0; c < 3; c++) o->Rcw[r][c] = vm[4 * c + r];
-  for (int k = 0; k < 3; k++) {
-    o->M[0][k] = o->Rcw[0][k] * o->J00 + o->Rcw[1][k] * 0.0f + o->Rcw[2][k] * o->J02;
-    o->M[1][k] = o->Rcw[0][k] * 0.0f + o->Rcw[1][k] * o->J11 + o->Rcw[2][k] * o->J12;
-  }
-  o->V[0][0] = c6[0]; o->V[0][1] = c6[1]; o->V[0][2] = c6[2];
-  o->V[1][0] = c6[1]; o->V[1][1] = c6[3]; o->V[1][2] = c6[4];
-  o->V[2][0] = c6[2]; o->V[2][1] = c6[4]; o->V[2][2] = c6[5];
-  float X[2][3];
-  for (int r = 0; r < 2; r++)
-    for (int c = 0; c < 3; c++) X[r][c] = o->M[r][0] * o->V[c][0] + o->M[r][1] * o->V[c][1] + o->M[r][2] * o->V[c][2];
-  o->a = (X[0][0] * o->M[0][0] + X[0][1] * o->M[0][1] + X[0][2] * o->M[0][2]) + 0.3f;
-  o->b = X[1][0] * o->M[0][0] + X[1][1] * o->M[0][1] + X[1][2] * o->M[0][2];
-  o->c = (X[1][0] * o->M[1][0] + X[1][1] * o->M[1][1] + X[1][2] * o->M[1][2]) + 0.3f;
 }
 
 /* SH basis -> RGB (+0.5, clamp at 0 with flags); forward.cu:22-73. sh is [M][3]. */
@@ -183,6 +170,8 @@ int gsaj_oracle_preprocess(int P, int D, int M, int W, int H,
   const float fy = (float)H / (2.0f * tanfovy), fx = (float)W / (2.0f * tanfovx);
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
   long R = 0;
+  int culled_prefiltered = 0;
+#pragma omp parallel for num_threads(g_threads) schedule(static) reduction(+ : R) reduction(| : culled_prefiltered)
   for (int i = 0; i < P; i++) {
     radii[i] = 0; tiles_touched[i] = 0;
     means2D[2 * i] = means2D[2 * i + 1] = 0.f; depths[i] = 0.f;
@@ -196,7 +185,7 @@ int gsaj_oracle_preprocess(int P, int D, int M, int W, int H,
     float pproj[3] = {ph[0] * pw, ph[1] * pw, ph[2] * pw};
     xform4x3(viewmatrix, p, pv);
     if (pv[2] <= 0.2f) {
-      if (prefiltered) return -1;
+      if (prefiltered) culled_prefiltered |= 1;
       continue;
     }
     const float *c6;
@@ -225,6 +214,7 @@ int gsaj_oracle_preprocess(int P, int D, int M, int W, int H,
     tiles_touched[i] = (y1 - y0) * (x1 - x0);
     R += tiles_touched[i];
   }
+  if (culled_prefiltered) return -1;
   return (int)R;
 }
 
@@ -238,7 +228,10 @@ void gsaj_oracle_mark_visible(int P, const float *means3D, const float *viewmatr
 }
 
 /* Stage 2: emit keys, stable sort by (tile, depth bits), tile ranges.
- * point_list[R]: Gaussian ids; ranges[2*tiles]: [start,end). rasterizer_impl.cu:70-138,339-368. */
+ * point_list[R]: Gaussian ids; ranges[2*tiles]: [start,end). rasterizer_impl.cu:70-138,339-368.
+ * The stable radix sort of the 64-bit keys is evaluated as: stable counting sort by tile id (keeps emission order),
+ * then a stable sort by depth bits inside every tile (ties keep emission order = Gaussian index order) -- the same
+ * permutation, and the tiles sort in parallel. */
 typedef struct { uint64_t key; uint32_t val; uint32_t seq; } KV;
 static int kv_cmp(const void *a, const void *b) {
   const KV *x = (const KV *)a, *y = (const KV *)b;
@@ -247,9 +240,22 @@ static int kv_cmp(const void *a, const void *b) {
 }
 int gsaj_oracle_bin(int P, int W, int H, int R, const int *radii, const float *means2D, const float *depths,
                     /* out */ uint32_t *point_list, uint64_t *keys_sorted, int *ranges) {
-  const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+  const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, tiles = gx * gy;
   KV *kv = (KV *)malloc(sizeof(KV) * (size_t)(R > 0 ? R : 1));
-  if (!kv) return -2;
+  uint32_t *start = (uint32_t *)calloc((size_t)tiles + 1, sizeof(uint32_t));
+  uint32_t *cursor = (uint32_t *)malloc(sizeof(uint32_t) * ((size_t)tiles + 1));
+  if (!kv || !start || !cursor) { free(kv); free(start); free(cursor); return -2; }
+  long total = 0;
+  for (int i = 0; i < P; i++) {
+    if (radii[i] <= 0) continue;
+    int x0, y0, x1, y1;
+    tile_rect(means2D[2 * i], means2D[2 * i + 1], radii[i], gx, gy, &x0, &y0, &x1, &y1);
+    for (int y = y0; y < y1; y++)
+      for (int x = x0; x < x1; x++) { start[y * gx + x + 1]++; total++; }
+  }
+  if (total != (long)R) { free(kv); free(start); free(cursor); return -3; }
+  for (int t = 0; t < tiles; t++) start[t + 1] += start[t];
+  memcpy(cursor, start, sizeof(uint32_t) * ((size_t)tiles + 1));
   uint32_t off = 0;
   for (int i = 0; i < P; i++) {
     if (radii[i] <= 0) continue;
@@ -259,73 +265,79 @@ int gsaj_oracle_bin(int P, int W, int H, int R, const int *radii, const float *m
     memcpy(&dbits, depths + i, 4);
     for (int y = y0; y < y1; y++)
       for (int x = x0; x < x1; x++) {
-        kv[off].key = ((uint64_t)(uint32_t)(y * gx + x) << 32) | dbits;
-        kv[off].val = (uint32_t)i; kv[off].seq = off; off++;
+        const uint32_t t = (uint32_t)(y * gx + x), k = cursor[t]++;
+        kv[k].key = ((uint64_t)t << 32) | dbits;
+        kv[k].val = (uint32_t)i; kv[k].seq = off++;
       }
   }
-  if ((int)off != R) { free(kv); return -3; }
-  qsort(kv, (size_t)R, sizeof(KV), kv_cmp);
-  memset(ranges, 0, sizeof(int) * 2 * (size_t)gx * gy);
-  for (int k = 0; k < R; k++) {
-    point_list[k] = kv[k].val;
-    if (keys_sorted) keys_sorted[k] = kv[k].key;
-    uint32_t cur = (uint32_t)(kv[k].key >> 32);
-    if (k == 0) ranges[2 * cur] = 0;
-    else {
-      uint32_t prev = (uint32_t)(kv[k - 1].key >> 32);
-      if (cur != prev) { ranges[2 * prev + 1] = k; ranges[2 * cur] = k; }
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 8)
+  for (int t = 0; t < tiles; t++) {
+    const uint32_t b = start[t], e = start[t + 1];
+    if (e > b + 1) qsort(kv + b, (size_t)(e - b), sizeof(KV), kv_cmp);
+    ranges[2 * t] = e > b ? (int)b : 0;
+    ranges[2 * t + 1] = e > b ? (int)e : 0;
+    for (uint32_t k = b; k < e; k++) {
+      point_list[k] = kv[k].val;
+      if (keys_sorted) keys_sorted[k] = kv[k].key;
     }
-    if (k == R - 1) ranges[2 * cur + 1] = R;
   }
-  free(kv);
+  free(kv); free(start); free(cursor);
   return 0;
 }
 
 /* Stage 3: per-pixel front-to-back compositing (forward.cu:406-535).
  * out_color [3,H,W], out_depth [H,W], out_opacity [H,W], final_T [H,W], n_contrib [H,W],
  * n_touched [P] (must be zeroed by caller). Returns sum over pixels of n_contrib
- * (= the interaction count I of SURVEY 8d). */
+ * (= the interaction count I of SURVEY 8d).  Tiles are independent (one thread per tile at a time). */
 long gsaj_oracle_render(int W, int H, const int *ranges, const uint32_t *point_list, const float *means2D,
                         const float *features, const float *conic_opacity, const float *depths, const float *bg,
                         float *out_color, float *out_depth, float *out_opacity, float *final_T,
                         uint32_t *n_contrib, int *n_touched) {
-  const int gx = (W + TILE - 1) / TILE;
+  const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
   long interactions = 0;
-  for (int py = 0; py < H; py++)
-    for (int px = 0; px < W; px++) {
-      int tile = (py / TILE) * gx + (px / TILE);
-      int beg = ranges[2 * tile], end = ranges[2 * tile + 1];
-      float T = 1.0f, C[3] = {0, 0, 0}, Dp = 0.0f;
-      uint32_t contributor = 0, last = 0;
-      float pxf = (float)px, pyf = (float)py;
-      for (int k = beg; k < end; k++) {
-        contributor++;
-        uint32_t g = point_list[k];
-        float dx = means2D[2 * g] - pxf, dy = means2D[2 * g + 1] - pyf;
-        const float *co = conic_opacity + 4 * g;
-        float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-        if (power > 0.0f) continue;
-        float alpha = fminf(0.99f, co[3] * expf(power));
-        if (alpha < 1.0f / 255.0f) continue;
-        float test_T = T * (1 - alpha);
-        if (test_T < 0.0001f) break;
-        for (int ch = 0; ch < 3; ch++) C[ch] += features[3 * g + ch] * alpha * T;
-        Dp += depths[g] * alpha * T;
-        if (test_T > 0.5f) n_touched[g]++;
-        T = test_T;
-        last = contributor;
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 4) reduction(+ : interactions)
+  for (int tile = 0; tile < gx * gy; tile++) {
+    const int ty = tile / gx, tx = tile - ty * gx;
+    const int beg = ranges[2 * tile], end = ranges[2 * tile + 1];
+    for (int py = ty * TILE; py < imin(H, (ty + 1) * TILE); py++)
+      for (int px = tx * TILE; px < imin(W, (tx + 1) * TILE); px++) {
+        float T = 1.0f, C[3] = {0, 0, 0}, Dp = 0.0f;
+        uint32_t contributor = 0, last = 0;
+        float pxf = (float)px, pyf = (float)py;
+        for (int k = beg; k < end; k++) {
+          contributor++;
+          uint32_t g = point_list[k];
+          float dx = means2D[2 * g] - pxf, dy = means2D[2 * g + 1] - pyf;
+          const float *co = conic_opacity + 4 * g;
+          float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+          if (power > 0.0f) continue;
+          float alpha = fminf(0.99f, co[3] * expf(power));
+          if (alpha < 1.0f / 255.0f) continue;
+          float test_T = T * (1 - alpha);
+          if (test_T < 0.0001f) break;
+          for (int ch = 0; ch < 3; ch++) C[ch] += features[3 * g + ch] * alpha * T;
+          Dp += depths[g] * alpha * T;
+          if (test_T > 0.5f) {
+#pragma omp atomic
+            n_touched[g]++;
+          }
+          T = test_T;
+          last = contributor;
+        }
+        size_t pid = (size_t)py * W + px;
+        final_T[pid] = T; n_contrib[pid] = last;
+        for (int ch = 0; ch < 3; ch++) out_color[(size_t)ch * H * W + pid] = C[ch] + T * bg[ch];
+        out_depth[pid] = Dp; out_opacity[pid] = 1 - T;
+        interactions += last;
       }
-      size_t pid = (size_t)py * W + px;
-      final_T[pid] = T; n_contrib[pid] = last;
-      for (int ch = 0; ch < 3; ch++) out_color[(size_t)ch * H * W + pid] = C[ch] + T * bg[ch];
-      out_depth[pid] = Dp; out_opacity[pid] = 1 - T;
-      interactions += last;
-    }
+  }
   return interactions;
 }
 
-/* Stage 4: reverse compositor (backward.cu:648-872).  Per-Gaussian sums are kept in
- * double and rounded once (the reference's float atomics have no defined order).
+/* Stage 4: reverse compositor (backward.cu:648-872).  The reference adds every pixel's 10 partials to the Gaussian's
+ * row with float atomics (no defined order).  Here every (tile, Gaussian) instance first gets its own double-precision
+ * partial sums (pixels of the tile in row-major order), then a Gaussian's instances are added in sorted-instance order
+ * and rounded once.
  * dL_dmean2D [P,3] (z unused), dL_dconic [P,4] (slots 0,1,3), dL_dopacity [P], dL_dcolor [P,3], dL_ddepth [P]. */
 void gsaj_oracle_render_backward(int P, int W, int H, const int *ranges, const uint32_t *point_list,
                                  const float *means2D, const float *conic_opacity, const float *colors,
@@ -333,66 +345,77 @@ void gsaj_oracle_render_backward(int P, int W, int H, const int *ranges, const u
                                  const uint32_t *n_contrib, const float *dL_dpix, const float *dL_dpix_depth,
                                  float *dL_dmean2D, float *dL_dconic, float *dL_dopacity, float *dL_dcolor,
                                  float *dL_ddepth) {
-  const int gx = (W + TILE - 1) / TILE;
+  const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+  int R = 0;
+  for (int t = 0; t < gx * gy; t++) R = imax(R, ranges[2 * t + 1]);
+  double *inst = (double *)calloc((size_t)(R > 0 ? R : 1) * 10, sizeof(double));
   double *acc = (double *)calloc((size_t)P * 10, sizeof(double));
   const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
-  for (int py = 0; py < H; py++)
-    for (int px = 0; px < W; px++) {
-      int tile = (py / TILE) * gx + (px / TILE);
-      int beg = ranges[2 * tile], end = ranges[2 * tile + 1];
-      size_t pid = (size_t)py * W + px;
-      const float T_final = final_T[pid];
-      float T = T_final;
-      int last = (int)n_contrib[pid];
-      float dLdC[3] = {dL_dpix[pid], dL_dpix[(size_t)H * W + pid], dL_dpix[2 * (size_t)H * W + pid]};
-      float dLdD = dL_dpix_depth[pid];
-      float accum_rec[3] = {0, 0, 0}, last_color[3] = {0, 0, 0};
-      float accum_rec_depth = 0, last_depth = 0, last_alpha = 0;
-      float pxf = (float)px, pyf = (float)py;
-      float bg_dot = 0.f;
-      for (int ch = 0; ch < 3; ch++) bg_dot += bg[ch] * dLdC[ch];
-      /* list position `contributor` (1-based) of entry k is k-beg+1; entries with
-       * contributor-1 >= last were never reached by the forward. */
-      for (int k = imin(end, beg + last) - 1; k >= beg; k--) {
-        uint32_t g = point_list[k];
-        float dx = means2D[2 * g] - pxf, dy = means2D[2 * g + 1] - pyf;
-        const float *co = conic_opacity + 4 * g;
-        float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-        if (power > 0.0f) continue;
-        float G = expf(power);
-        float alpha = fminf(0.99f, co[3] * G);
-        if (alpha < 1.0f / 255.0f) continue;
-        T = T / (1.f - alpha);
-        float dchannel_dcolor = alpha * T;
-        float dL_dalpha = 0.0f;
-        double *a = acc + (size_t)g * 10;
-        for (int ch = 0; ch < 3; ch++) {
-          float c = colors[3 * g + ch];
-          accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
-          last_color[ch] = c;
-          dL_dalpha += (c - accum_rec[ch]) * dLdC[ch];
-          a[6 + ch] += (double)(dchannel_dcolor * dLdC[ch]);
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 4)
+  for (int tile = 0; tile < gx * gy; tile++) {
+    const int ty = tile / gx, tx = tile - ty * gx;
+    const int beg = ranges[2 * tile], end = ranges[2 * tile + 1];
+    for (int py = ty * TILE; py < imin(H, (ty + 1) * TILE); py++)
+      for (int px = tx * TILE; px < imin(W, (tx + 1) * TILE); px++) {
+        size_t pid = (size_t)py * W + px;
+        const float T_final = final_T[pid];
+        float T = T_final;
+        int last = (int)n_contrib[pid];
+        float dLdC[3] = {dL_dpix[pid], dL_dpix[(size_t)H * W + pid], dL_dpix[2 * (size_t)H * W + pid]};
+        float dLdD = dL_dpix_depth[pid];
+        float accum_rec[3] = {0, 0, 0}, last_color[3] = {0, 0, 0};
+        float accum_rec_depth = 0, last_depth = 0, last_alpha = 0;
+        float pxf = (float)px, pyf = (float)py;
+        float bg_dot = 0.f;
+        for (int ch = 0; ch < 3; ch++) bg_dot += bg[ch] * dLdC[ch];
+        /* list position `contributor` (1-based) of entry k is k-beg+1; entries with
+         * contributor-1 >= last were never reached by the forward. */
+        for (int k = imin(end, beg + last) - 1; k >= beg; k--) {
+          uint32_t g = point_list[k];
+          float dx = means2D[2 * g] - pxf, dy = means2D[2 * g + 1] - pyf;
+          const float *co = conic_opacity + 4 * g;
+          float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+          if (power > 0.0f) continue;
+          float G = expf(power);
+          float alpha = fminf(0.99f, co[3] * G);
+          if (alpha < 1.0f / 255.0f) continue;
+          T = T / (1.f - alpha);
+          float dchannel_dcolor = alpha * T;
+          float dL_dalpha = 0.0f;
+          double *a = inst + (size_t)k * 10;
+          for (int ch = 0; ch < 3; ch++) {
+            float c = colors[3 * g + ch];
+            accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
+            last_color[ch] = c;
+            dL_dalpha += (c - accum_rec[ch]) * dLdC[ch];
+            a[6 + ch] += (double)(dchannel_dcolor * dLdC[ch]);
+          }
+          float depth = depths[g];
+          accum_rec_depth = last_alpha * last_depth + (1.f - last_alpha) * accum_rec_depth;
+          last_depth = depth;
+          dL_dalpha += (depth - accum_rec_depth) * dLdD;
+          a[9] += (double)(dchannel_dcolor * dLdD);
+          dL_dalpha *= T;
+          last_alpha = alpha;
+          dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+          float dL_dG = co[3] * dL_dalpha;
+          float gdx = G * dx, gdy = G * dy;
+          float dG_ddelx = -gdx * co[0] - gdy * co[1];
+          float dG_ddely = -gdy * co[2] - gdx * co[1];
+          a[0] += (double)(dL_dG * dG_ddelx * ddelx_dx);
+          a[1] += (double)(dL_dG * dG_ddely * ddely_dy);
+          a[2] += (double)(-0.5f * gdx * dx * dL_dG);
+          a[3] += (double)(-0.5f * gdx * dy * dL_dG);
+          a[4] += (double)(-0.5f * gdy * dy * dL_dG);
+          a[5] += (double)(G * dL_dalpha);
         }
-        float depth = depths[g];
-        accum_rec_depth = last_alpha * last_depth + (1.f - last_alpha) * accum_rec_depth;
-        last_depth = depth;
-        dL_dalpha += (depth - accum_rec_depth) * dLdD;
-        a[9] += (double)(dchannel_dcolor * dLdD);
-        dL_dalpha *= T;
-        last_alpha = alpha;
-        dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
-        float dL_dG = co[3] * dL_dalpha;
-        float gdx = G * dx, gdy = G * dy;
-        float dG_ddelx = -gdx * co[0] - gdy * co[1];
-        float dG_ddely = -gdy * co[2] - gdx * co[1];
-        a[0] += (double)(dL_dG * dG_ddelx * ddelx_dx);
-        a[1] += (double)(dL_dG * dG_ddely * ddely_dy);
-        a[2] += (double)(-0.5f * gdx * dx * dL_dG);
-        a[3] += (double)(-0.5f * gdx * dy * dL_dG);
-        a[4] += (double)(-0.5f * gdy * dy * dL_dG);
-        a[5] += (double)(G * dL_dalpha);
       }
-    }
+  }
+  for (int k = 0; k < R; k++) { /* serial: a Gaussian's instances in sorted-instance order */
+    double *a = acc + (size_t)point_list[k] * 10;
+    const double *b = inst + (size_t)k * 10;
+    for (int c = 0; c < 10; c++) a[c] += b[c];
+  }
   for (int g = 0; g < P; g++) {
     const double *a = acc + (size_t)g * 10;
     dL_dmean2D[3 * g] = (float)a[0]; dL_dmean2D[3 * g + 1] = (float)a[1]; dL_dmean2D[3 * g + 2] = 0.f;
@@ -402,219 +425,189 @@ void gsaj_oracle_render_backward(int P, int W, int H, const int *ranges, const u
     dL_ddepth[g] = (float)a[9];
   }
   free(acc);
+  free(inst);
 }
 
-static void cross3(const float *a, const float *b, float *o) {
-  o[0] = a[1] * b[2] - a[2] * b[1];
-  o[1] = a[2] * b[0] - a[0] * b[2];
-  o[2] = a[0] * b[1] - a[1] * b[0];
-}
+/* ------------------------------------------------------------------------------------------------------------
+ * Error model of the reverse compositor's per-Gaussian sums (TEST ANALYSIS, not part of the restated algorithm).
+ *
+ * Two correct fp32 implementations of backward.cu:648-872 (this oracle, the reference's CUDA kernel, the HIP kernels)
+ * differ in three ways, each bounded here per Gaussian and per output component c (order: mean2D x,y, conic a,b,c,
+ * opacity, colour r,g,b, depth):
+ *   term_mass[g,c]   = sum over pixels of |term|: a different summation order / accumulator width moves the sum by at
+ *                      most (a small multiple of eps) * term_mass;
+ *   cond_slack[g,c]  = sum over pixels of |term| * eps * (1 + mag + n), mag = (|a| dx^2 + |c| dy^2)/2 + |b dx dy|: power =
+ *                      -(a dx^2 + c dy^2)/2 - b dx dy is a difference of products that cancel for elongated, rotated
+ *                      Gaussians, so ANY fp32 evaluation of alpha = o exp(power) has a relative error of a few eps * mag;
+ *                      n = how many contributors the walk has already un-blended at that pixel: T is recovered by
+ *                      repeated division T <- T / (1 - alpha) (backward.cu:779), each adding a rounding of its own;
+ *   flip_budget[g,c] = sum over BORDERLINE pixels of |term(all borderline decisions taken one way) - term(taken the other
+ *                      way)|, where a pixel is borderline if some entry's alpha is within (border_rel + 4 eps mag) of 1/255,
+ *                      T(1-alpha) within the accumulated relative uncertainty of 1e-4, or power within its rounding of 0:
+ *                      there the cut-offs of forward.cu:406-535 may legitimately fall either way, and the whole pixel's
+ *                      backward (this entry, the nearer ones through accum_rec, the farther ones through T, the last
+ *                      contributor and T_final) is re-evaluated both ways, forward and backward.
+ *   border_mask[pix] = 1 for those pixels (the image / n_contrib checks allow differences only there).
+ * All arrays are outputs; P-major [P,10] floats, border_mask [H*W] bytes. */
+typedef struct {
+  const uint32_t *point_list; const float *means2D, *conic_opacity, *colors, *depths, *bg;
+  float ddelx_dx, ddely_dy, border_rel, border_rel_T;
+} EMScene;
 
-/* d(v/|v|)/dv applied to dv (auxiliary.h:109-119). */
-static void dnormvdv3(const float *v, const float *dv, float *o) {
-  float sum2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
-  float inv = 1.0f / sqrtf(sum2 * sum2 * sum2);
-  o[0] = ((+sum2 - v[0] * v[0]) * dv[0] - v[1] * v[0] * dv[1] - v[2] * v[0] * dv[2]) * inv;
-  o[1] = (-v[0] * v[1] * dv[0] + (sum2 - v[1] * v[1]) * dv[1] - v[2] * v[1] * dv[2]) * inv;
-  o[2] = (-v[0] * v[2] * dv[0] - v[1] * v[2] * dv[1] + (sum2 - v[2] * v[2]) * dv[2]) * inv;
-}
-
-/* SH backward: dL/dsh, dL/dmean (view-direction path) and tau[0:3] -= dL/dmean (backward.cu:21-145). */
-static void sh_backward(int deg, int M, const float *pos, const float *campos, const float *sh,
-                        const uint8_t *clamped, const float *dL_dcolor, float *dL_dmean_acc, float *dL_dsh,
-                        float *dL_dtau) {
-  float dorig[3] = {pos[0] - campos[0], pos[1] - campos[1], pos[2] - campos[2]};
-  float len = sqrtf(dorig[0] * dorig[0] + dorig[1] * dorig[1] + dorig[2] * dorig[2]);
-  float x = dorig[0] / len, y = dorig[1] / len, z = dorig[2] / len;
-  float g[3];
-  for (int ch = 0; ch < 3; ch++) g[ch] = dL_dcolor[ch] * (clamped[ch] ? 0.f : 1.f);
-  float dx[3] = {0, 0, 0}, dy[3] = {0, 0, 0}, dz[3] = {0, 0, 0};
-  (void)M;
-#define SH(k, ch) sh[(k) * 3 + (ch)]
-#define OUT(k, w) for (int ch = 0; ch < 3; ch++) dL_dsh[(k) * 3 + ch] = (w) * g[ch];
-  OUT(0, SH_C0)
-  if (deg > 0) {
-    OUT(1, -SH_C1 * y) OUT(2, SH_C1 * z) OUT(3, -SH_C1 * x)
-    for (int ch = 0; ch < 3; ch++) { dx[ch] = -SH_C1 * SH(3, ch); dy[ch] = -SH_C1 * SH(1, ch); dz[ch] = SH_C1 * SH(2, ch); }
-    if (deg > 1) {
-      float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-      OUT(4, SH_C2[0] * xy) OUT(5, SH_C2[1] * yz) OUT(6, SH_C2[2] * (2.f * zz - xx - yy))
-      OUT(7, SH_C2[3] * xz) OUT(8, SH_C2[4] * (xx - yy))
-      for (int ch = 0; ch < 3; ch++) {
-        dx[ch] += SH_C2[0] * y * SH(4, ch) + SH_C2[2] * 2.f * -x * SH(6, ch) + SH_C2[3] * z * SH(7, ch) + SH_C2[4] * 2.f * x * SH(8, ch);
-        dy[ch] += SH_C2[0] * x * SH(4, ch) + SH_C2[1] * z * SH(5, ch) + SH_C2[2] * 2.f * -y * SH(6, ch) + SH_C2[4] * 2.f * -y * SH(8, ch);
-        dz[ch] += SH_C2[1] * y * SH(5, ch) + SH_C2[2] * 2.f * 2.f * z * SH(6, ch) + SH_C2[3] * x * SH(7, ch);
-      }
-      if (deg > 2) {
-        OUT(9, SH_C3[0] * y * (3.f * xx - yy)) OUT(10, SH_C3[1] * xy * z) OUT(11, SH_C3[2] * y * (4.f * zz - xx - yy))
-        OUT(12, SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)) OUT(13, SH_C3[4] * x * (4.f * zz - xx - yy))
-        OUT(14, SH_C3[5] * z * (xx - yy)) OUT(15, SH_C3[6] * x * (xx - 3.f * yy))
-        for (int ch = 0; ch < 3; ch++) {
-          dx[ch] += (SH_C3[0] * SH(9, ch) * 3.f * 2.f * xy + SH_C3[1] * SH(10, ch) * yz + SH_C3[2] * SH(11, ch) * -2.f * xy +
-                     SH_C3[3] * SH(12, ch) * -3.f * 2.f * xz + SH_C3[4] * SH(13, ch) * (-3.f * xx + 4.f * zz - yy) +
-                     SH_C3[5] * SH(14, ch) * 2.f * xz + SH_C3[6] * SH(15, ch) * 3.f * (xx - yy));
-          dy[ch] += (SH_C3[0] * SH(9, ch) * 3.f * (xx - yy) + SH_C3[1] * SH(10, ch) * xz +
-                     SH_C3[2] * SH(11, ch) * (-3.f * yy + 4.f * zz - xx) + SH_C3[3] * SH(12, ch) * -3.f * 2.f * yz +
-                     SH_C3[4] * SH(13, ch) * -2.f * xy + SH_C3[5] * SH(14, ch) * -2.f * yz + SH_C3[6] * SH(15, ch) * -3.f * 2.f * xy);
-          dz[ch] += (SH_C3[1] * SH(10, ch) * xy + SH_C3[2] * SH(11, ch) * 4.f * 2.f * yz +
-                     SH_C3[3] * SH(12, ch) * 3.f * (2.f * zz - xx - yy) + SH_C3[4] * SH(13, ch) * 4.f * 2.f * xz +
-                     SH_C3[5] * SH(14, ch) * (xx - yy));
-        }
-      }
-    }
+/* forward walk of one pixel with borderline decisions biased: +1 include / continue, -1 exclude / stop, 0 as computed.
+ * Returns 1 if a borderline decision was met. */
+static int em_forward(const EMScene *sc, int beg, int end, float pxf, float pyf, int bias, float *T_out, int *last_out) {
+  const double eps = 1.1920929e-07, thr = 1.0 / 255.0;
+  float T = 1.0f;
+  int last = 0, border = 0;
+  double t_rel = sc->border_rel_T;
+  for (int k = beg; k < end; k++) {
+    uint32_t g = sc->point_list[k];
+    float dx = sc->means2D[2 * g] - pxf, dy = sc->means2D[2 * g + 1] - pyf;
+    const float *co = sc->conic_opacity + 4 * g;
+    float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+    double mag = 0.5 * (fabs((double)co[0]) * dx * dx + fabs((double)co[2]) * dy * dy) + fabs((double)co[1] * dx * dy);
+    double a_rel = sc->border_rel + 4.0 * eps * mag;
+    int skip = power > 0.0f;
+    if (fabs((double)power) <= 4.0 * eps * mag + 1e-7) { border = 1; if (bias) skip = bias < 0; }
+    if (skip) continue;
+    float alpha = fminf(0.99f, co[3] * expf(fminf(power, 0.0f)));
+    int low = alpha < 1.0f / 255.0f;
+    if (fabs((double)alpha - thr) <= a_rel * thr) { border = 1; if (bias) low = bias < 0; }
+    if (low) continue;
+    float test_T = T * (1 - alpha);
+    t_rel += a_rel * alpha / (1.0 - alpha);
+    int stop = test_T < 0.0001f;
+    if (fabs((double)test_T - 1e-4) <= t_rel * 1e-4) { border = 1; if (bias) stop = bias < 0; }
+    if (stop) break;
+    T = test_T;
+    last = k - beg + 1;
   }
-#undef SH
-#undef OUT
-  float ddir[3] = {dx[0] * g[0] + dx[1] * g[1] + dx[2] * g[2], dy[0] * g[0] + dy[1] * g[1] + dy[2] * g[2],
-                   dz[0] * g[0] + dz[1] * g[1] + dz[2] * g[2]};
-  float dmean[3];
-  dnormvdv3(dorig, ddir, dmean);
-  for (int k = 0; k < 3; k++) { dL_dmean_acc[k] += dmean[k]; dL_dtau[k] += -dmean[k]; }
+  *T_out = T; *last_out = last;
+  return border;
 }
 
-/* Stage 5: per-Gaussian backward -- conic -> cov2D -> (cov3D, mean3D, tau), mean2D -> (mean3D, tau),
- * depth -> (mean3D, tau), colour -> (SH, mean3D, tau), cov3D -> (scale, rot).
- * backward.cu:150-345 (computeCov2DCUDA), :494-624 (preprocessCUDA), :426-489 (computeCov3D).
- * Outputs must be zero-initialised by the caller (rows of culled Gaussians stay zero). */
-void gsaj_oracle_preprocess_backward(int P, int D, int M, int W, int H, const float *means3D, const int *radii,
-                                     const float *shs, const uint8_t *clamped, const float *scales,
-                                     const float *rotations, float scale_modifier, const float *cov3Ds,
-                                     const float *viewmatrix, const float *projmatrix, const float *projmatrix_raw,
-                                     const float *campos, float tanfovx, float tanfovy, const float *dL_dmean2D,
-                                     const float *dL_dconic, const float *dL_dcolor, const float *dL_ddepth,
-                                     float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh, float *dL_dscale,
-                                     float *dL_drot, float *dL_dtau) {
-  const float fy = (float)H / (2.0f * tanfovy), fx = (float)W / (2.0f * tanfovx);
-  for (int i = 0; i < P; i++) {
-    if (!(radii[i] > 0)) continue;
-    const float *mean = means3D + 3 * i;
-    float *tau = dL_dtau + 6 * i;
-    /* ---- conic -> cov2D -> cov3D / T / J / t ---- */
-    Cov2D cv;
-    cov2d_eval(mean, fx, fy, tanfovx, tanfovy, cov3Ds + 6 * i, viewmatrix, &cv);
-    const float xmul = (cv.txtz < -cv.limx || cv.txtz > cv.limx) ? 0.f : 1.f;
-    const float ymul = (cv.tytz < -cv.limy || cv.tytz > cv.limy) ? 0.f : 1.f;
-    float gcx = dL_dconic[4 * i], gcy = dL_dconic[4 * i + 1], gcz = dL_dconic[4 * i + 3];
-    float a = cv.a, b = cv.b, c = cv.c;
-    float denom = a * c - b * b;
-    float dL_da = 0, dL_db = 0, dL_dc = 0;
-    float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
-    float (*Mx)[3] = cv.M;
-    float *gcov = dL_dcov3D + 6 * i;
-    if (denom2inv != 0) {
-      dL_da = denom2inv * (-c * c * gcx + 2 * b * c * gcy + (denom - a * c) * gcz);
-      dL_dc = denom2inv * (-a * a * gcz + 2 * a * b * gcy + (denom - a * c) * gcx);
-      dL_db = denom2inv * 2 * (b * c * gcx - (denom + 2 * b * b) * gcy + a * b * gcz);
-      gcov[0] = (Mx[0][0] * Mx[0][0] * dL_da + Mx[0][0] * Mx[1][0] * dL_db + Mx[1][0] * Mx[1][0] * dL_dc);
-      gcov[3] = (Mx[0][1] * Mx[0][1] * dL_da + Mx[0][1] * Mx[1][1] * dL_db + Mx[1][1] * Mx[1][1] * dL_dc);
-      gcov[5] = (Mx[0][2] * Mx[0][2] * dL_da + Mx[0][2] * Mx[1][2] * dL_db + Mx[1][2] * Mx[1][2] * dL_dc);
-      gcov[1] = 2 * Mx[0][0] * Mx[0][1] * dL_da + (Mx[0][0] * Mx[1][1] + Mx[0][1] * Mx[1][0]) * dL_db + 2 * Mx[1][0] * Mx[1][1] * dL_dc;
-      gcov[2] = 2 * Mx[0][0] * Mx[0][2] * dL_da + (Mx[0][0] * Mx[1][2] + Mx[0][2] * Mx[1][0]) * dL_db + 2 * Mx[1][0] * Mx[1][2] * dL_dc;
-      gcov[4] = 2 * Mx[0][2] * Mx[0][1] * dL_da + (Mx[0][1] * Mx[1][2] + Mx[0][2] * Mx[1][1]) * dL_db + 2 * Mx[1][1] * Mx[1][2] * dL_dc;
-    } else {
-      for (int k = 0; k < 6; k++) gcov[k] = 0;
+/* backward walk of one pixel under the same bias; adds the 10 terms of every visited entry k to v[(k-beg)*10 + c]
+ * and, if m / cs are given, |term| and |term| * eps * mag. */
+static void em_backward(const EMScene *sc, int beg, int end, float pxf, float pyf, int bias, float T_final, int last,
+                        const float *dLdC, float dLdD, double *v, double *m, double *cs) {
+  const double eps = 1.1920929e-07, thr = 1.0 / 255.0;
+  float T = T_final, accum_rec[3] = {0, 0, 0}, last_color[3] = {0, 0, 0};
+  float accum_rec_depth = 0, last_depth = 0, last_alpha = 0, bg_dot = 0.f;
+  double ndiv = 0.0;
+  for (int ch = 0; ch < 3; ch++) bg_dot += sc->bg[ch] * dLdC[ch];
+  for (int k = imin(end, beg + last) - 1; k >= beg; k--) {
+    uint32_t g = sc->point_list[k];
+    float dx = sc->means2D[2 * g] - pxf, dy = sc->means2D[2 * g + 1] - pyf;
+    const float *co = sc->conic_opacity + 4 * g;
+    float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+    double mag = 0.5 * (fabs((double)co[0]) * dx * dx + fabs((double)co[2]) * dy * dy) + fabs((double)co[1] * dx * dy);
+    double a_rel = sc->border_rel + 4.0 * eps * mag;
+    int skip = power > 0.0f;
+    if (bias && fabs((double)power) <= 4.0 * eps * mag + 1e-7) skip = bias < 0;
+    if (skip) continue;
+    float G = expf(fminf(power, 0.0f));
+    float alpha = fminf(0.99f, co[3] * G);
+    int low = alpha < 1.0f / 255.0f;
+    if (bias && fabs((double)alpha - thr) <= a_rel * thr) low = bias < 0;
+    if (low) continue;
+    T = T / (1.f - alpha);
+    ndiv += 1.0;
+    float dchannel_dcolor = alpha * T, dL_dalpha = 0.0f;
+    double t[10];
+    for (int ch = 0; ch < 3; ch++) {
+      float c = sc->colors[3 * g + ch];
+      accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
+      last_color[ch] = c;
+      dL_dalpha += (c - accum_rec[ch]) * dLdC[ch];
+      t[6 + ch] = (double)(dchannel_dcolor * dLdC[ch]);
     }
-    /* dL/dM (2x3): MV[r][k] = sum_j M[r][j] V[k][j] */
-    float MV[2][3], dM[2][3];
-    for (int r = 0; r < 2; r++)
-      for (int k = 0; k < 3; k++) MV[r][k] = Mx[r][0] * cv.V[k][0] + Mx[r][1] * cv.V[k][1] + Mx[r][2] * cv.V[k][2];
-    for (int k = 0; k < 3; k++) {
-      dM[0][k] = 2 * MV[0][k] * dL_da + MV[1][k] * dL_db;
-      dM[1][k] = 2 * MV[1][k] * dL_dc + MV[0][k] * dL_db;
-    }
-    /* M = J Rcw  ->  dL/dJ[i][j] = sum_k dM[i][k] Rcw[j][k] */
-    float (*Rc)[3] = cv.Rcw;
-    float dJ00 = Rc[0][0] * dM[0][0] + Rc[0][1] * dM[0][1] + Rc[0][2] * dM[0][2];
-    float dJ02 = Rc[2][0] * dM[0][0] + Rc[2][1] * dM[0][1] + Rc[2][2] * dM[0][2];
-    float dJ11 = Rc[1][0] * dM[1][0] + Rc[1][1] * dM[1][1] + Rc[1][2] * dM[1][2];
-    float dJ12 = Rc[2][0] * dM[1][0] + Rc[2][1] * dM[1][1] + Rc[2][2] * dM[1][2];
-    float tz = 1.f / cv.t[2], tz2 = tz * tz, tz3 = tz2 * tz;
-    float gt[3];
-    gt[0] = xmul * -fx * tz2 * dJ02;
-    gt[1] = ymul * -fy * tz2 * dJ12;
-    gt[2] = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2 * fx * cv.t[0]) * tz3 * dJ02 + (2 * fy * cv.t[1]) * tz3 * dJ12;
-    /* tau: rho += g, theta += t x g  with the CLAMPED t (backward.cu:275-290) */
-    float txg[3];
-    cross3(cv.t, gt, txg);
-    for (int k = 0; k < 3; k++) { tau[k] += gt[k]; tau[3 + k] += txg[k]; }
-    /* mean3D (covariance part) = Rcw^T g; assignment, not += (backward.cu:300) */
-    float *gm = dL_dmean3D + 3 * i;
-    for (int k = 0; k < 3; k++) gm[k] = Rc[0][k] * gt[0] + Rc[1][k] * gt[1] + Rc[2][k] * gt[2];
-    /* dL/dRcw[j][k] = sum_i J[i][j] dM[i][k]; theta += sum_k col_k(Rcw) x col_k(dL/dRcw) (backward.cu:301-345) */
-    float dR[3][3];
-    for (int k = 0; k < 3; k++) {
-      dR[0][k] = cv.J00 * dM[0][k];
-      dR[1][k] = cv.J11 * dM[1][k];
-      dR[2][k] = cv.J02 * dM[0][k] + cv.J12 * dM[1][k];
-    }
-    float th[3] = {0, 0, 0};
-    for (int k = 0; k < 3; k++) {
-      float ck[3] = {Rc[0][k], Rc[1][k], Rc[2][k]}, gk[3] = {dR[0][k], dR[1][k], dR[2][k]}, cr[3];
-      cross3(ck, gk, cr);
-      /* reference evaluates dot(g_k, (-[c_k]x).col_m): same value, keep its sum order over k */
-      th[0] += cr[0]; th[1] += cr[1]; th[2] += cr[2];
-    }
-    for (int k = 0; k < 3; k++) tau[3 + k] += th[k];
-
-    /* ---- mean2D -> mean3D and tau (backward.cu:512-597) ---- */
-    float mh[4];
-    xform4x4(projmatrix, mean, mh);
-    float mw = 1.0f / (mh[3] + 0.0000001f);
-    const float *pj = projmatrix;
-    float g2x = dL_dmean2D[3 * i], g2y = dL_dmean2D[3 * i + 1];
-    float mul1 = (pj[0] * mean[0] + pj[4] * mean[1] + pj[8] * mean[2] + pj[12]) * mw * mw;
-    float mul2 = (pj[1] * mean[0] + pj[5] * mean[1] + pj[9] * mean[2] + pj[13]) * mw * mw;
-    gm[0] += (pj[0] * mw - pj[3] * mul1) * g2x + (pj[1] * mw - pj[3] * mul2) * g2y;
-    gm[1] += (pj[4] * mw - pj[7] * mul1) * g2x + (pj[5] * mw - pj[7] * mul2) * g2y;
-    gm[2] += (pj[8] * mw - pj[11] * mul1) * g2x + (pj[9] * mw - pj[11] * mul2) * g2y;
-    float alpha_ = 1.0f * mw, beta_ = -mh[0] * mw * mw, gamma_ = -mh[1] * mw * mw;
-    float pa = projmatrix_raw[0], pb = projmatrix_raw[5], pe = projmatrix_raw[11];
-    float pC[3];
-    xform4x3(viewmatrix, mean, pC); /* un-clamped camera-space point */
-    float d1[3] = {alpha_ * pa, 0.f, beta_ * pe}, d2[3] = {0.f, alpha_ * pb, gamma_ * pe};
-    float c1[3], c2[3];
-    cross3(pC, d1, c1); /* (-[p]x)^T d = p x d */
-    cross3(pC, d2, c2);
-    for (int k = 0; k < 3; k++) {
-      tau[k] += g2x * d1[k] + g2y * d2[k];
-      tau[3 + k] += g2x * c1[k] + g2y * c2[k];
-    }
-    /* ---- depth -> mean3D and tau (backward.cu:599-613): dz/dtau = [0,0,1, y, -x, 0] ---- */
-    float gz = dL_ddepth[i];
-    gm[0] += gz * viewmatrix[2]; gm[1] += gz * viewmatrix[6]; gm[2] += gz * viewmatrix[10];
-    tau[2] += gz * 1.f;
-    tau[3] += gz * pC[1];
-    tau[4] += gz * -pC[0];
-    tau[5] += gz * 0.f;
-    /* ---- colour -> SH, view direction -> mean3D and tau ---- */
-    if (shs) sh_backward(D, M, mean, campos, shs + (size_t)i * M * 3, clamped + 3 * i, dL_dcolor + 3 * i, gm,
-                         dL_dsh + (size_t)i * M * 3, tau);
-    /* ---- cov3D -> scale, rotation (backward.cu:426-489) ---- */
-    if (scales) {
-      float R[3][3], s[3] = {scale_modifier * scales[3 * i], scale_modifier * scales[3 * i + 1], scale_modifier * scales[3 * i + 2]};
-      const float *q = rotations + 4 * i;
-      quat_to_R(q, R);
-      float dS[3][3] = {{gcov[0], 0.5f * gcov[1], 0.5f * gcov[2]},
-                        {0.5f * gcov[1], gcov[3], 0.5f * gcov[4]},
-                        {0.5f * gcov[2], 0.5f * gcov[4], gcov[5]}};
-      /* A = S R^T (A[i][j] = s_i R[j][i]); dL/dA = 2 A dSigma */
-      float dA[3][3];
-      for (int r = 0; r < 3; r++)
-        for (int cc = 0; cc < 3; cc++) {
-          float v = 0;
-          for (int k = 0; k < 3; k++) v += (s[r] * R[k][r]) * dS[k][cc];
-          dA[r][cc] = 2.0f * v;
-        }
-      for (int k = 0; k < 3; k++) dL_dscale[3 * i + k] = R[0][k] * dA[k][0] + R[1][k] * dA[k][1] + R[2][k] * dA[k][2];
-      /* dL/dR[j][i] = s_i dA[i][j] */
-      float g[3][3];
-      for (int ii = 0; ii < 3; ii++)
-        for (int j = 0; j < 3; j++) g[j][ii] = s[ii] * dA[ii][j];
-      float r = q[0], x = q[1], y = q[2], z = q[3];
-      dL_drot[4 * i + 0] = 2 * z * (g[1][0] - g[0][1]) + 2 * y * (g[0][2] - g[2][0]) + 2 * x * (g[2][1] - g[1][2]);
-      dL_drot[4 * i + 1] = 2 * y * (g[0][1] + g[1][0]) + 2 * z * (g[0][2] + g[2][0]) + 2 * r * (g[2][1] - g[1][2]) - 4 * x * (g[2][2] + g[1][1]);
-      dL_drot[4 * i + 2] = 2 * x * (g[0][1] + g[1][0]) + 2 * r * (g[0][2] - g[2][0]) + 2 * z * (g[2][1] + g[1][2]) - 4 * y * (g[2][2] + g[0][0]);
-      dL_drot[4 * i + 3] = 2 * r * (g[1][0] - g[0][1]) + 2 * x * (g[0][2] + g[2][0]) + 2 * y * (g[2][1] + g[1][2]) - 4 * z * (g[1][1] + g[0][0]);
+    float depth = sc->depths[g];
+    accum_rec_depth = last_alpha * last_depth + (1.f - last_alpha) * accum_rec_depth;
+    last_depth = depth;
+    dL_dalpha += (depth - accum_rec_depth) * dLdD;
+    t[9] = (double)(dchannel_dcolor * dLdD);
+    dL_dalpha *= T;
+    last_alpha = alpha;
+    dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+    float dL_dG = co[3] * dL_dalpha, gdx = G * dx, gdy = G * dy;
+    t[0] = (double)(dL_dG * (-gdx * co[0] - gdy * co[1]) * sc->ddelx_dx);
+    t[1] = (double)(dL_dG * (-gdy * co[2] - gdx * co[1]) * sc->ddely_dy);
+    t[2] = (double)(-0.5f * gdx * dx * dL_dG);
+    t[3] = (double)(-0.5f * gdx * dy * dL_dG);
+    t[4] = (double)(-0.5f * gdy * dy * dL_dG);
+    t[5] = (double)(G * dL_dalpha);
+    double *vk = v + (size_t)(k - beg) * 10;
+    for (int c = 0; c < 10; c++) vk[c] += t[c];
+    if (m) {
+      double *mk = m + (size_t)(k - beg) * 10, *ck = cs + (size_t)(k - beg) * 10;
+      const double adG = fabs((double)dL_dG);
+      double a[10];
+      a[0] = adG * (fabs((double)(gdx * co[0])) + fabs((double)(gdy * co[1]))) * sc->ddelx_dx;  /* a sum of two products */
+      a[1] = adG * (fabs((double)(gdy * co[2])) + fabs((double)(gdx * co[1]))) * sc->ddely_dy;
+      for (int c = 2; c < 10; c++) a[c] = fabs(t[c]);
+      for (int c = 0; c < 10; c++) { mk[c] += a[c]; ck[c] += a[c] * eps * (1.0 + mag + ndiv); }
     }
   }
 }
+
+void gsaj_oracle_error_model(int P, int W, int H, const int *ranges, const uint32_t *point_list, const float *means2D,
+                             const float *conic_opacity, const float *colors, const float *depths, const float *bg,
+                             const float *dL_dpix, const float *dL_dpix_depth, float border_rel, float border_rel_T,
+                             float *term_mass, float *cond_slack, float *flip_budget, uint8_t *border_mask) {
+  const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+  int R = 0;
+  for (int t = 0; t < gx * gy; t++) R = imax(R, ranges[2 * t + 1]);
+  const size_t Rn = (size_t)(R > 0 ? R : 1) * 10;
+  double *im = (double *)calloc(Rn, sizeof(double)), *ic = (double *)calloc(Rn, sizeof(double));
+  double *ifl = (double *)calloc(Rn, sizeof(double));
+  EMScene sc = {point_list, means2D, conic_opacity, colors, depths, bg, 0.5f * W, 0.5f * H, border_rel, border_rel_T};
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 4)
+  for (int tile = 0; tile < gx * gy; tile++) {
+    const int ty = tile / gx, tx = tile - ty * gx;
+    const int beg = ranges[2 * tile], end = ranges[2 * tile + 1], n = end - beg;
+    double *scratch = (double *)malloc(sizeof(double) * 10 * (size_t)(n > 0 ? n : 1) * 3);
+    double *v0 = scratch, *vp = scratch + 10 * (size_t)(n > 0 ? n : 1), *vm = vp + 10 * (size_t)(n > 0 ? n : 1);
+    for (int py = ty * TILE; py < imin(H, (ty + 1) * TILE); py++)
+      for (int px = tx * TILE; px < imin(W, (tx + 1) * TILE); px++) {
+        size_t pid = (size_t)py * W + px;
+        float dLdC[3] = {dL_dpix[pid], dL_dpix[(size_t)H * W + pid], dL_dpix[2 * (size_t)H * W + pid]};
+        float dLdD = dL_dpix_depth[pid], Tf;
+        int last;
+        const int border = em_forward(&sc, beg, end, (float)px, (float)py, 0, &Tf, &last);
+        border_mask[pid] = (uint8_t)border;
+        if (n <= 0) continue;
+        memset(v0, 0, sizeof(double) * 10 * (size_t)n);
+        em_backward(&sc, beg, end, (float)px, (float)py, 0, Tf, last, dLdC, dLdD, v0, im + (size_t)beg * 10, ic + (size_t)beg * 10);
+        if (border) {
+          float Tp, Tm;
+          int lp, lm;
+          memset(vp, 0, sizeof(double) * 10 * (size_t)n * 2);
+          em_forward(&sc, beg, end, (float)px, (float)py, +1, &Tp, &lp);
+          em_backward(&sc, beg, end, (float)px, (float)py, +1, Tp, lp, dLdC, dLdD, vp, NULL, NULL);
+          em_forward(&sc, beg, end, (float)px, (float)py, -1, &Tm, &lm);
+          em_backward(&sc, beg, end, (float)px, (float)py, -1, Tm, lm, dLdC, dLdD, vm, NULL, NULL);
+          for (size_t i = 0; i < (size_t)n * 10; i++)
+            ifl[(size_t)beg * 10 + i] += fmax(fabs(vp[i] - vm[i]), fmax(fabs(vp[i] - v0[i]), fabs(vm[i] - v0[i])));
+        }
+      }
+    free(scratch);
+  }
+  double *acc = (double *)calloc((size_t)P * 30, sizeof(double));
+  for (int k = 0; k < R; k++) {
+    const size_t g = point_list[k];
+    for (int c = 0; c < 10; c++) {
+      acc[g * 30 + c] += im[(size_t)k * 10 + c];
+      acc[g * 30 + 10 + c] += ic[(size_t)k * 10 + c];
+      acc[g * 30 + 20 + c] += ifl[(size_t)k * 10 + c];
+    }
+  }
+  for (size_t g = 0; g < (size_t)P; g++)
+    for (int c = 0; c < 10; c++) {
+      term_mass[g * 10 + c] = (float)acc[g * 30 + c];
+      cond_slack[g * 10 + c] = (float)acc[g * 30 + 10 + c];
+      flip_budget[g * 10 + c] = (float)acc[g * 30 + 20 + c];
+    }
+  free(acc); free(im); free(ic); free(ifl);
+}
+

@@ -1,8 +1,10 @@
 """GPU parity of the tiled rasteriser (forward + analytical-Jacobian backward) against the CPU
-oracle, through the C ABI.  Tolerances: integers and indices exact; fp32 images rtol 2e-4
-(of the array's max); gradients 2e-3 of the array's max (the oracle sums per-Gaussian
-contributions in fp64, the kernels in fp32 with a different association order, and use
-v_exp_f32 / v_rcp_f32 where the oracle uses libm expf and a true division)."""
+oracle, through the C ABI.  Tolerances (tests/helpers.py): integers and indices exact; n_contrib and
+images may differ only at pixels whose oracle walk meets a cut-off borderline contributor (each such
+pixel is verified), all other pixels within IMG_TOL = 2e-5 of the image's max; every gradient within
+GRAD_TOL = 1e-4 of its tensor's max and every row within ROW_TOL = 1e-3 of its own magnitude (the oracle
+sums per-Gaussian contributions in fp64, the kernels in fp32 with a different association order, and
+use v_exp_f32 / v_rcp_f32 where the oracle uses libm expf and a true division)."""
 import numpy as np
 import pytest
 
@@ -10,8 +12,8 @@ import helpers as hp
 
 pytestmark = pytest.mark.gpu
 
-IMG_TOL = 2e-4
-GRAD_TOL = 2e-3
+IMG_TOL = hp.IMG_TOL
+GRAD_TOL = hp.GRAD_TOL
 
 
 @pytest.fixture(scope="module")
@@ -47,31 +49,19 @@ def test_forward_and_backward_parity(torch_cuda, name, precomp):
         assert hp.rel_err(dbg["rgb"][vis], st["rgb"][vis]) < 1e-5
         np.testing.assert_array_equal(dbg["clamped"][vis], st["clamped"][vis])
         assert hp.rel_err(dbg["cov3D"][vis], st["cov3D"][vis]) < 1e-6
-    # integer image-space outputs: exact up to threshold-borderline pixels (v_exp_f32 vs expf)
-    nc = dbg["n_contrib"].astype(np.int64)
-    assert (nc != st["n_contrib"].astype(np.int64)).mean() <= 1e-4
+    # integer image-space outputs: exact except at pixels with a cut-off borderline contributor (v_exp_f32 vs expf)
+    tag = "%s/%s" % (name, "precomp" if precomp else "sh")
+    hp.assert_counts_close(dbg["n_contrib"], st["n_contrib"], st, tag=tag)
     assert np.abs(n_touched.cpu().numpy().astype(np.int64) - ref["n_touched"]).sum() <= max(2, 1e-4 * ref["n_touched"].sum())
-    for got, want in ((color, ref["color"]), (depth, ref["depth"]), (opacity, ref["opacity"]), (dbg["final_T"], st["final_T"])):
+    for nm, got, want in (("color", color, ref["color"]), ("depth", depth, ref["depth"]), ("opacity", opacity, ref["opacity"]),
+                          ("final_T", dbg["final_T"], st["final_T"])):
         got = got.cpu().numpy() if hasattr(got, "cpu") else got
-        hp.assert_image_close(got.reshape(want.shape), want, IMG_TOL)
+        hp.assert_image_close(got.reshape(want.shape), want, IMG_TOL, st=st, tag=tag + "/" + nm)
 
     dLc, dLd = hp.seeds(cam, seed=1)
-    gref = __import__("oracle.oracle", fromlist=["backward"]).backward(st, dLc, dLd, cam["projmatrix_raw"])
-    g = hp.gpu_backward(cam, deg, out, args, dLc, dLd)
-    (m2, dcol, dop, m3, dcov, dsh, dscale, drot, dtau, dtau_sum, dconic, ddepth) = [
-        None if x is None else x.cpu().numpy() for x in g]
-    pairs = [("dL_dmean2D", m2), ("dL_dcolor", dcol), ("dL_dopacity", dop), ("dL_dmean3D", m3), ("dL_dcov3D", dcov),
-             ("dL_dtau", dtau), ("dL_dconic", dconic), ("dL_ddepth", ddepth)]
-    if not precomp:
-        pairs += [("dL_dsh", dsh), ("dL_dscale", dscale), ("dL_drot", drot)]
-    for key, got in pairs:
-        want = gref[key]
-        if np.abs(want).max() == 0:
-            assert np.abs(got).max() == 0, key
-            continue
-        assert hp.rel_err(got.reshape(want.shape), want) < GRAD_TOL, (key, hp.rel_err(got.reshape(want.shape), want))
-    assert hp.rel_err(dtau_sum, gref["dL_dtau_sum"]) < GRAD_TOL
-    assert hp.rel_err(dtau.astype(np.float64).sum(0), dtau_sum) < 1e-4
+    g, gref = hp.check_backward(cam, deg, out, args, st, dLc, dLd, tag)
+    dtau, dtau_sum = g[8].cpu().numpy(), g[9].cpu().numpy()
+    assert hp.rel_err(dtau.astype(np.float64).sum(0), dtau_sum) < 1e-5
 
 
 def test_bitwise_reproducible(torch_cuda):
@@ -160,7 +150,7 @@ def test_render_api_autograd_and_pose_update(torch_cuda):
     ref, st = orc.forward(f(model.get_xyz), f(model.get_opacity), f(view.world_view_transform), f(view.full_proj_transform),
                           f(view.camera_center), cam["tanfovx"], cam["tanfovy"], cam["W"], cam["H"], np.zeros(3, np.float32),
                           shs=f(model.get_features), scales=f(model.get_scaling), rotations=f(model.get_rotation), sh_degree=3)
-    hp.assert_image_close(f(pkg["render"]), ref["color"], IMG_TOL)
+    hp.assert_image_close(f(pkg["render"]), ref["color"], IMG_TOL, st=st)
     g = orc.backward(st, f(wc) / wc.numel(), f(wd) / wd.numel(), f(view.projection_matrix))
     tau = g["dL_dtau_sum"]
     assert hp.rel_err(f(view.cam_trans_delta.grad), tau[:3]) < GRAD_TOL
@@ -259,12 +249,9 @@ def test_global_sort_fallback_path(torch_cuda, mode):
     dbg = {k: v.cpu().numpy() for k, v in C.debug_export(sc["means3D"].shape[0], R, cam["W"], cam["H"], geom, binning, img).items()}
     np.testing.assert_array_equal(dbg["point_list"].astype(np.uint32), st["point_list"])
     np.testing.assert_array_equal(dbg["ranges"], st["ranges"])
-    hp.assert_image_close(color.cpu().numpy(), ref["color"], IMG_TOL)
+    hp.assert_image_close(color.cpu().numpy(), ref["color"], IMG_TOL, st=st)
     dLc, dLd = hp.seeds(cam, seed=3)
-    gref = orc.backward(st, dLc, dLd, cam["projmatrix_raw"])
-    g = hp.gpu_backward(cam, deg, out, args, dLc, dLd)
-    assert hp.rel_err(g[9].cpu().numpy(), gref["dL_dtau_sum"]) < GRAD_TOL
-    assert hp.rel_err(g[3].cpu().numpy(), gref["dL_dmean3D"]) < GRAD_TOL
+    g, gref = hp.check_backward(cam, deg, out, args, st, dLc, dLd, "global_sort/" + mode)
 
 
 def test_async_forward_matches_sync_and_reports_overflow(torch_cuda):
