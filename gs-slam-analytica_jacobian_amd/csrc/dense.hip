@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void k_dense_bwd(int N, int W, int H, const fl
                                                    const float *__restrict__ covs2D, const float *__restrict__ colors,
                                                    const float *__restrict__ depths, const float *__restrict__ opac,
                                                    const float *__restrict__ seed_color,
-                                                   const float *__restrict__ seed_depth, float *__restrict__ slab) {
+                                                   const float *__restrict__ seed_depth, float *__restrict__ slab, int naive) {
   __shared__ float par[DCHUNK * DPAR];
   __shared__ float acc[DCHUNK * 4 * IGRAD_F];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -96,6 +96,8 @@ __global__ __launch_bounds__(256) void k_dense_bwd(int N, int W, int H, const fl
       const float alpha = dense_alpha(p, u, v, dx, dy, qx, qy, rx, ry);
       const float aT = alpha * T;
       const float den = alpha < 0.999f ? 1.0f - alpha : 1.0f;
+      // naive-loop semantics (GSAJ_DENSE_NAIVE_GUARDS): at alpha >= 0.999 the suffix term is dropped, not divided by 1
+      const float keep = (naive && !(alpha < 0.999f)) ? 0.0f : 1.0f;
       float dLda = 0.f;
 #pragma unroll
       for (int ch = 0; ch < 4; ch++) {
@@ -103,9 +105,10 @@ __global__ __launch_bounds__(256) void k_dense_bwd(int N, int W, int H, const fl
         pre[ch] += (double)(val * aT);
         const float after = (float)(tot[ch] - pre[ch]);
         const float g = ch < 3 ? gC[ch] : gD;
-        dLda += g * (val * T - after / den);
+        dLda += g * (val * T - keep * (after / den));
       }
-      const float w = inside ? dLda * alpha : 0.f;
+      // (naive loop: an entry with abs(alpha) < 1e-8 adds nothing to dL/dmu, dL/dSigma)
+      const float w = (inside && !(naive && fabsf(alpha) < 1e-8f)) ? dLda * alpha : 0.f;
       const float m = inside ? aT : 0.f;
       float vals[10];
       vals[0] = w * qx; vals[1] = w * qy;                          // dL/dmu
@@ -301,6 +304,83 @@ __device__ __forceinline__ void sh_dbasis16(int deg, double x, double y, double 
   }
 }
 
+// ---- NumPy-path front end: project, colour and depth-order the Gaussians (fp64 on fp32 inputs, like the reference's
+// Python floats) -- GetImagePlaneMeanAndCovs + compute_cov2d + ndc2Pix + compute_colors_from_sh + OrderGaussiansByDepth
+// (Loss_Derivative_script_compare.py:854-971, :772-848, :851-852, :535-588, :764-769).  A.4 semantics: NO z <= 0.2 cull,
+// NO radius / tile test, colours clamped below at 0 only, ONE global stable depth order.
+__global__ __launch_bounds__(128) void k_dense_project(int N, int M, int deg, const float *__restrict__ means3D,
+                                                       const float *__restrict__ cov3D6, const float *__restrict__ shs,
+                                                       const float *__restrict__ vm, const float *__restrict__ pm,
+                                                       const float *__restrict__ campos, double fx, double fy, double tanx,
+                                                       double tany, int W, int H, double *__restrict__ mean2D,
+                                                       double *__restrict__ cov2D, double *__restrict__ color,
+                                                       double *__restrict__ color_raw, double *__restrict__ depth) {
+  const int i = blockIdx.x * 128 + threadIdx.x;
+  if (i >= N) return;
+  const double x = means3D[3 * i], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
+  // the rasteriser's transposed matrices: flat index 4*c + r = element (r, c) of W2C / P W2C
+  double ph[4], t[3];
+  for (int r = 0; r < 4; r++) ph[r] = (double)pm[r] * x + (double)pm[4 + r] * y + (double)pm[8 + r] * z + (double)pm[12 + r];
+  for (int r = 0; r < 3; r++) t[r] = (double)vm[r] * x + (double)vm[4 + r] * y + (double)vm[8 + r] * z + (double)vm[12 + r];
+  const double pw = ph[3] + 0.0000001;
+  mean2D[2 * i] = ((ph[0] / pw + 1.0) * W - 1.0) * 0.5;
+  mean2D[2 * i + 1] = ((ph[1] / pw + 1.0) * H - 1.0) * 0.5;
+  depth[i] = t[2];
+  const double limx = 1.3 * tanx, limy = 1.3 * tany;
+  const double tx = fmin(limx, fmax(-limx, t[0] / t[2])) * t[2], ty = fmin(limy, fmax(-limy, t[1] / t[2])) * t[2];
+  const double J[2][3] = {{fx / t[2], 0.0, -(fx * tx) / (t[2] * t[2])}, {0.0, fy / t[2], -(fy * ty) / (t[2] * t[2])}};
+  double T[2][3];  // T = J W, W[r][c] = element (r, c) of the rotation block of W2C
+  for (int r = 0; r < 2; r++)
+    for (int c = 0; c < 3; c++) T[r][c] = J[r][0] * (double)vm[4 * c + 0] + J[r][1] * (double)vm[4 * c + 1] + J[r][2] * (double)vm[4 * c + 2];
+  const float *c6 = cov3D6 + 6 * (size_t)i;
+  const double V[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+  double TV[2][3];
+  for (int r = 0; r < 2; r++)
+    for (int c = 0; c < 3; c++) TV[r][c] = T[r][0] * V[0][c] + T[r][1] * V[1][c] + T[r][2] * V[2][c];
+  for (int r = 0; r < 2; r++)
+    for (int c = 0; c < 2; c++)
+      cov2D[4 * i + 2 * r + c] = TV[r][0] * T[c][0] + TV[r][1] * T[c][1] + TV[r][2] * T[c][2] + (r == c ? 0.3 : 0.0);
+  // colours: SH (degree `deg`, M coefficients stored) at the world-frame direction (gaussian - camera) / (|.| + 1e-8)
+  const double d0 = x - (double)campos[0], d1 = y - (double)campos[1], d2 = z - (double)campos[2];
+  const double nrm = sqrt(d0 * d0 + d1 * d1 + d2 * d2) + 1e-8;
+  double B[16];
+  sh_basis16(deg, d0 / nrm, d1 / nrm, d2 / nrm, B);
+  for (int ch = 0; ch < 3; ch++) {
+    double raw = 0.5;
+    for (int k = 0; k < M && k < 16; k++) raw += B[k] * (double)shs[((size_t)i * M + k) * 3 + ch];
+    color_raw[3 * i + ch] = raw;
+    color[3 * i + ch] = raw < 0.0 ? 0.0 : raw;
+  }
+}
+
+// rank of every Gaussian in the global stable depth order (Python's list.sort is stable: ties keep index order).
+// N is small on this path (every Gaussian meets every pixel), so the O(N^2) count with an LDS-staged key block is ample.
+__global__ __launch_bounds__(256) void k_dense_rank(int N, const double *__restrict__ depth, int *__restrict__ order) {
+  __shared__ double zs[256];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const double zi = i < N ? depth[i] : 0.0;
+  int rank = 0;
+  for (int base = 0; base < N; base += 256) {
+    __syncthreads();
+    if (base + threadIdx.x < N) zs[threadIdx.x] = depth[base + threadIdx.x];
+    __syncthreads();
+    const int n = min(256, N - base);
+    for (int j = 0; j < n; j++) {
+      const double zj = zs[j];
+      rank += (zj < zi || (zj == zi && base + j < i)) ? 1 : 0;
+    }
+  }
+  if (i < N) order[rank] = i;
+}
+
+__global__ __launch_bounds__(256) void k_dense_gather(int N, const int *__restrict__ order, const double *__restrict__ in,
+                                                      double *__restrict__ out, int width) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= N * width) return;
+  const int r = t / width, c = t - r * width;
+  out[t] = in[(size_t)order[r] * width + c];
+}
+
 __global__ __launch_bounds__(256) void k_dense_tau(int N, int M, int deg, const int *__restrict__ order,
                                                    const float *__restrict__ g_mu, const float *__restrict__ g_S,
                                                    const float *__restrict__ g_z, const float *__restrict__ g_c,
@@ -381,7 +461,7 @@ size_t gsaj_dense_workspace_bytes(int N, int W, int H) {
 int gsaj_dense_backward(int N, int W, int H, const float *means2D, const float *covs2D, const float *colors,
                         const float *depths, const float *opac, const float *seed_color, const float *seed_depth,
                         float *grad_mu, float *grad_Sigma, float *grad_depth, float *grad_color, void *dense_ws,
-                        void *stream) {
+                        int flags, void *stream) {
   if (N <= 0 || W <= 0 || H <= 0 || !means2D || !covs2D || !colors || !depths || !opac || !seed_color || !seed_depth ||
       !grad_mu || !grad_Sigma || !grad_depth || !grad_color || !dense_ws) {
     gsaj_set_error("gsaj_dense_backward: invalid argument");
@@ -393,7 +473,7 @@ int gsaj_dense_backward(int N, int W, int H, const float *means2D, const float *
   {
     GsajProfScope ps(ST_DENSE_BWD, s);
     hipLaunchKernelGGL(k_dense_bwd, dim3(nblk), dim3(256), 0, s, N, W, H, means2D, covs2D, colors, depths, opac, seed_color,
-                       seed_depth, slab);
+                       seed_depth, slab, (flags & GSAJ_DENSE_NAIVE_GUARDS) ? 1 : 0);
   }
   GsajProfScope ps(ST_DENSE_REDUCE, s);
   hipLaunchKernelGGL(k_dense_reduce, dim3((N * 10 + 255) / 256), dim3(256), 0, s, N, nblk, slab, grad_mu, grad_Sigma,
@@ -411,6 +491,36 @@ int gsaj_dense_render(int N, int W, int H, const float *means2D, const float *co
   const int nblk = (int)(((size_t)W * H + 255) / 256);
   hipLaunchKernelGGL(k_dense_render, dim3(nblk), dim3(256), 0, (hipStream_t)stream, N, W, H, means2D, covs2D, colors,
                      depths, opac, out_color, out_depth);
+  GSAJ_HIP_CHECK(hipGetLastError());
+  return GSAJ_OK;
+}
+
+size_t gsaj_dense_project_workspace_bytes(int N) { return sizeof(double) * 13 * (size_t)(N > 0 ? N : 1) + 256; }
+
+int gsaj_dense_project(int N, int sh_coeffs, int sh_degree, int W, int H, const float *means3D, const float *cov3D,
+                       const float *shs, const float *viewmatrix, const float *projmatrix, const float *campos, double fx,
+                       double fy, int *order, double *mean2D, double *cov2D, double *color, double *color_raw, double *depth,
+                       void *project_ws, void *stream) {
+  if (N <= 0 || W <= 0 || H <= 0 || !means3D || !cov3D || !shs || sh_coeffs <= 0 || sh_coeffs > 16 || sh_degree < 0 ||
+      (sh_degree + 1) * (sh_degree + 1) > sh_coeffs || !viewmatrix || !projmatrix || !campos || !order || !mean2D || !cov2D ||
+      !color || !depth || !project_ws) {
+    gsaj_set_error("gsaj_dense_project: invalid argument");
+    return GSAJ_ERR_INVALID_ARGUMENT;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  double *w = reinterpret_cast<double *>(gsaj_align(reinterpret_cast<size_t>(project_ws)));
+  const size_t n = (size_t)N;
+  double *u_mean = w, *u_cov = w + 2 * n, *u_col = w + 6 * n, *u_raw = w + 9 * n, *u_dep = w + 12 * n;
+  hipLaunchKernelGGL(k_dense_project, dim3((N + 127) / 128), dim3(128), 0, s, N, sh_coeffs, sh_degree, means3D, cov3D, shs,
+                     viewmatrix, projmatrix, campos, fx, fy, W / (2.0 * fx), H / (2.0 * fy), W, H, u_mean, u_cov, u_col, u_raw,
+                     u_dep);
+  hipLaunchKernelGGL(k_dense_rank, dim3((N + 255) / 256), dim3(256), 0, s, N, u_dep, order);
+  const struct { const double *in; double *out; int width; } cols[5] = {
+      {u_mean, mean2D, 2}, {u_cov, cov2D, 4}, {u_col, color, 3}, {u_raw, color_raw, 3}, {u_dep, depth, 1}};
+  for (int k = 0; k < 5; k++)
+    if (cols[k].out)
+      hipLaunchKernelGGL(k_dense_gather, dim3((N * cols[k].width + 255) / 256), dim3(256), 0, s, N, order, cols[k].in, cols[k].out,
+                         cols[k].width);
   GSAJ_HIP_CHECK(hipGetLastError());
   return GSAJ_OK;
 }

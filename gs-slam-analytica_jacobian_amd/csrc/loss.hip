@@ -23,6 +23,7 @@ struct LossParams {
   float *dL_dcolor, *dL_ddepth, *dL_dopacity;
   float *partials;    // [nblocks][4]
   uint32_t *ticket;   // zero between launches (reset by the last workgroup)
+  const uint32_t *n_valid;  // COMPUTE_LOSS: number of pixels with gt_depth > 0 inside the mask (k_count_valid)
   float *out;         // [5]: loss, L_rgb, L_depth, dL/da, dL/db
 };
 
@@ -33,8 +34,13 @@ __global__ __launch_bounds__(LOSS_BLOCK) void k_loss_seeds(LossParams p) {
   __shared__ bool is_last;
   const size_t HW = (size_t)p.W * p.H;
   const bool tracking = p.flags & GSAJ_LOSS_TRACKING, mono = p.flags & GSAJ_LOSS_MONOCULAR, noexp = p.flags & GSAJ_LOSS_NO_EXPOSURE;
+  // compute_loss of the verification harness (Jacobian_test.py:155-196): mask given per pixel, colour term = mean over
+  // 3HW, depth term = mean over the valid pixels only, plain sum of the two (no alpha weighting, no exposure)
+  const bool cl = p.flags & GSAJ_LOSS_COMPUTE_LOSS;
   const float ea = noexp ? 1.f : expf(p.exp_a[0]), eb = noexp ? 0.f : p.exp_b[0];
-  const float k_rgb = (mono ? 1.f : p.alpha) / (3.f * (float)HW), k_d = (1.f - p.alpha) / (float)HW;
+  const float nv = cl ? (float)max(p.n_valid[0], 1u) : 0.f;
+  const float k_rgb = cl ? 1.f / (3.f * (float)HW) : (mono ? 1.f : p.alpha) / (3.f * (float)HW);
+  const float k_d = cl ? 1.f / nv : (1.f - p.alpha) / (float)HW;
   float s_rgb = 0.f, s_d = 0.f, s_a = 0.f, s_b = 0.f;
 #pragma unroll
   for (int q = 0; q < LOSS_PPT; q++) {
@@ -43,8 +49,8 @@ __global__ __launch_bounds__(LOSS_BLOCK) void k_loss_seeds(LossParams p) {
     const float g0 = p.gt_color[pix], g1 = p.gt_color[HW + pix], g2 = p.gt_color[2 * HW + pix];
     const float c0 = p.color[pix], c1 = p.color[HW + pix], c2 = p.color[2 * HW + pix];
     const float op = p.opacity[pix];
-    float m = (g0 + g1 + g2 > p.rgb_thr) ? 1.f : 0.f;
-    if (tracking && p.grad_mask) m = p.grad_mask[pix] ? m : 0.f;
+    float m = (cl || g0 + g1 + g2 > p.rgb_thr) ? 1.f : 0.f;
+    if ((tracking || cl) && p.grad_mask) m = p.grad_mask[pix] ? m : 0.f;
     const float wrgb = tracking ? op : 1.f;
     const float r0 = (ea * c0 + eb) * m - g0 * m, r1 = (ea * c1 + eb) * m - g1 * m, r2 = (ea * c2 + eb) * m - g2 * m;
     const float a0 = fabsf(r0), a1 = fabsf(r1), a2 = fabsf(r2);
@@ -59,8 +65,9 @@ __global__ __launch_bounds__(LOSS_BLOCK) void k_loss_seeds(LossParams p) {
     float dd = 0.f;
     if (!mono) {
       const float gd = p.gt_depth[pix], d = p.depth[pix];
-      float dm = (gd > 0.01f) ? 1.f : 0.f;
+      float dm = (gd > (cl ? 0.0f : 0.01f)) ? 1.f : 0.f;
       if (tracking) dm = (op > 0.95f) ? dm : 0.f;
+      if (cl) dm *= m;
       const float rd = d * dm - gd * dm;
       s_d += fabsf(rd);
       dd = k_d * dm * sgn(rd);
@@ -131,14 +138,25 @@ __global__ __launch_bounds__(LOSS_BLOCK) void k_loss_seeds(LossParams p) {
       for (int w = 1; w < LOSS_BLOCK / 64; w++) t[c] += fin[c][w];
     }
     const double n_rgb = 3.0 * (double)HW;
-    const double l_rgb = t[0] / n_rgb, l_d = mono ? 0.0 : t[1] / (double)HW;
-    p.out[0] = (float)(mono ? l_rgb : (double)p.alpha * l_rgb + (1.0 - (double)p.alpha) * l_d);
+    const double l_rgb = t[0] / n_rgb, l_d = mono ? 0.0 : t[1] / (cl ? (double)max(p.n_valid[0], 1u) : (double)HW);
+    p.out[0] = (float)(cl ? (mono ? l_rgb : l_rgb + l_d) : mono ? l_rgb : (double)p.alpha * l_rgb + (1.0 - (double)p.alpha) * l_d);
     p.out[1] = (float)l_rgb;
     p.out[2] = (float)l_d;
     p.out[3] = noexp ? 0.f : (float)((double)k_rgb * t[2]);
     p.out[4] = noexp ? 0.f : (float)((double)k_rgb * t[3]);
     *p.ticket = 0u;
   }
+}
+
+// number of pixels with gt_depth > 0 inside the mask (the denominator of compute_loss's depth term): integer atomics
+__global__ __launch_bounds__(LOSS_BLOCK) void k_count_valid(size_t HW, const float *__restrict__ gt_depth,
+                                                            const uint8_t *__restrict__ mask, uint32_t *__restrict__ count) {
+  uint32_t c = 0;
+  for (size_t i = (size_t)blockIdx.x * LOSS_BLOCK + threadIdx.x; i < HW; i += (size_t)gridDim.x * LOSS_BLOCK)
+    c += (gt_depth[i] > 0.0f && (!mask || mask[i])) ? 1u : 0u;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
 }
 
 extern "C" size_t gsaj_loss_workspace_bytes(int W, int H) {
@@ -153,10 +171,11 @@ extern "C" int gsaj_loss_seeds(int W, int H, int flags, float alpha, float rgb_b
                                void *loss_ws, void *stream) {
   const bool mono = flags & GSAJ_LOSS_MONOCULAR, noexp = flags & GSAJ_LOSS_NO_EXPOSURE;
   if (W <= 0 || H <= 0 || !color || !opacity || !gt_color || !dL_dcolor || !dL_ddepth || !out_scalars || !loss_ws ||
-      (!mono && (!depth || !gt_depth)) || (!noexp && (!exposure_a || !exposure_b))) {
+      (!mono && (!depth || !gt_depth)) || (!noexp && !(flags & GSAJ_LOSS_COMPUTE_LOSS) && (!exposure_a || !exposure_b))) {
     gsaj_set_error("gsaj_loss_seeds: invalid argument (W=%d H=%d flags=%d)", W, H, flags);
     return GSAJ_ERR_INVALID_ARGUMENT;
   }
+  if (flags & GSAJ_LOSS_COMPUTE_LOSS) flags |= GSAJ_LOSS_NO_EXPOSURE;
   LossParams p;
   p.W = W; p.H = H; p.flags = flags; p.alpha = alpha; p.rgb_thr = rgb_boundary_threshold;
   p.color = color; p.depth = depth; p.opacity = opacity; p.gt_color = gt_color; p.gt_depth = gt_depth;
@@ -166,8 +185,79 @@ extern "C" int gsaj_loss_seeds(int W, int H, int flags, float alpha, float rgb_b
   p.ticket = (uint32_t *)base;          // the caller zeroes the workspace once, when it allocates it
   p.partials = (float *)(base + 256);
   p.out = out_scalars;
+  p.n_valid = (uint32_t *)(base + 64);
+  if ((flags & GSAJ_LOSS_COMPUTE_LOSS) && !mono) {
+    GSAJ_HIP_CHECK(hipMemsetAsync(base + 64, 0, sizeof(uint32_t), (hipStream_t)stream));
+    hipLaunchKernelGGL(k_count_valid, dim3(64), dim3(LOSS_BLOCK), 0, (hipStream_t)stream, (size_t)W * H, gt_depth, grad_mask,
+                       (uint32_t *)(base + 64));
+  }
   const unsigned nblk = (unsigned)(((size_t)W * H + LOSS_BLOCK * LOSS_PPT - 1) / (LOSS_BLOCK * LOSS_PPT));
   hipLaunchKernelGGL(k_loss_seeds, dim3(nblk), dim3(LOSS_BLOCK), 0, (hipStream_t)stream, p);
+  GSAJ_HIP_CHECK(hipGetLastError());
+  return GSAJ_OK;
+}
+
+// ---- isotropic regulariser: weight * mean |s_ij - mean_j(s_i.)| over [P,3] scales, and its gradient -----------------
+// (compute_loss, Jacobian_test.py:169-171: weight 10; the mapping loss, slam_backend.py:229-231).  Deterministic: workgroup
+// partials in fp64, summed in workgroup order by the last-arriving workgroup.
+__global__ __launch_bounds__(LOSS_BLOCK) void k_isotropic(int P, int C, float weight, const float *__restrict__ scales,
+                                                          float *__restrict__ dL_dscales, int accumulate,
+                                                          double *__restrict__ partials, uint32_t *__restrict__ ticket,
+                                                          float *__restrict__ out) {
+  __shared__ double red[LOSS_BLOCK / 64];
+  __shared__ bool is_last;
+  const int i = blockIdx.x * LOSS_BLOCK + threadIdx.x;
+  const float k = weight / ((float)P * (float)C);
+  double s = 0.0;
+  if (i < P) {
+    float v[3] = {0.f, 0.f, 0.f}, m = 0.f;
+    for (int c = 0; c < C; c++) { v[c] = scales[(size_t)i * C + c]; m += v[c]; }
+    m /= (float)C;
+    float sg[3], ssum = 0.f;
+    for (int c = 0; c < C; c++) {
+      const float d = v[c] - m;
+      s += (double)fabsf(d);
+      sg[c] = sgn(d);
+      ssum += sg[c];
+    }
+    if (dL_dscales)
+      for (int c = 0; c < C; c++) {
+        const float gq = k * (sg[c] - ssum / (float)C);
+        dL_dscales[(size_t)i * C + c] = accumulate ? dL_dscales[(size_t)i * C + c] + gq : gq;
+      }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = red[0];
+    for (int w = 1; w < LOSS_BLOCK / 64; w++) t += red[w];
+    __hip_atomic_store(&partials[blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    is_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!is_last || threadIdx.x != 0) return;
+  double t = 0.0;
+  for (unsigned b = 0; b < gridDim.x; b++) t += __hip_atomic_load(&partials[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  out[0] = (float)((double)k * t);
+  *ticket = 0u;
+}
+
+extern "C" size_t gsaj_isotropic_workspace_bytes(int P) {
+  return 512 + sizeof(double) * (size_t)((P + LOSS_BLOCK - 1) / LOSS_BLOCK + 1);
+}
+
+extern "C" int gsaj_isotropic_loss(int P, int C, float weight, const float *scales, float *dL_dscales, int accumulate,
+                                   float *out_loss, void *iso_ws, void *stream) {
+  if (P <= 0 || C < 1 || C > 3 || !scales || !out_loss || !iso_ws) {
+    gsaj_set_error("gsaj_isotropic_loss: invalid argument (P=%d C=%d)", P, C);
+    return GSAJ_ERR_INVALID_ARGUMENT;
+  }
+  char *base = (char *)(((uintptr_t)iso_ws + 255) & ~(uintptr_t)255);
+  hipLaunchKernelGGL(k_isotropic, dim3((P + LOSS_BLOCK - 1) / LOSS_BLOCK), dim3(LOSS_BLOCK), 0, (hipStream_t)stream, P, C, weight,
+                     scales, dL_dscales, accumulate, (double *)(base + 256), (uint32_t *)base, out_loss);
   GSAJ_HIP_CHECK(hipGetLastError());
   return GSAJ_OK;
 }

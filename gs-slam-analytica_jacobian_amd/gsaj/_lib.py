@@ -42,7 +42,9 @@ SIGNATURES = {
     "gsaj_profile_begin": (c_int, [c_int]),
     "gsaj_profile_end": (c_int, [P, P]),
     "gsaj_dense_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "gsaj_dense_backward": (c_int, [c_int, c_int, c_int] + [P] * 7 + [P] * 4 + [P, P]),
+    "gsaj_dense_backward": (c_int, [c_int, c_int, c_int] + [P] * 7 + [P] * 4 + [P, c_int, P]),
+    "gsaj_dense_project_workspace_bytes": (c_size_t, [c_int]),
+    "gsaj_dense_project": (c_int, [c_int] * 5 + [P] * 6 + [c_double, c_double] + [P] * 6 + [P, P]),
     "gsaj_dense_render": (c_int, [c_int, c_int, c_int] + [P] * 5 + [P, P, P]),
     "gsaj_pose_jacobians": (c_int, [c_int, P, P, P, c_double, c_double, c_int, c_int, P, P, P]),
     "gsaj_dense_tau": (c_int, [c_int, c_int, c_int] + [P] * 11 + [P, P, P]),
@@ -51,6 +53,8 @@ SIGNATURES = {
     "gsaj_pose_state_floats": (c_int, []),
     "gsaj_pose_adam_step": (c_int, [P, P] + [c_float] * 8 + [P, P, P]),
     "gsaj_loss_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "gsaj_isotropic_workspace_bytes": (c_size_t, [c_int]),
+    "gsaj_isotropic_loss": (c_int, [c_int, c_int, c_float, P, P, c_int, P, P, P]),
     "gsaj_loss_seeds": (c_int, [c_int, c_int, c_int, c_float, c_float] + [P] * 8 + [P] * 4 + [P, P]),
 }
 

@@ -3,7 +3,12 @@
 Mirrors the functions of Loss_Derivative_script_compare.py that produce the committed goldens
 grad_mu_I_pixel.npy, grad_Sigma_I_pixel.npy, grad_depth_per_gaussian.npy and dL_dtau.npy:
 
-  compute_gradients_2D(...)                    <- compute_gradients_2D_vectorized_chunked (:1173-1351)
+  project_and_sort(...)                        <- OrderGaussiansByDepth (:764-769) + GetImagePlaneMeanAndCovs (:854-971)
+                                                  with compute_cov2d (:772-848), ndc2Pix (:851-852), SH colours (:535-588)
+  compute_gradients_2D(...)                    <- compute_gradients_2D_vectorized_chunked (:1173-1351);
+                                                  naive_guards=True: the naive loop's edge branches (:1050-1169, wrt.py:3-118)
+  jacobian_test(...)                           <- the __main__ pipeline (:1354-1706): world Gaussians + camera + ground truth
+                                                  -> grad_mu_I, grad_Sigma_I, grad_depth_per_gaussian, dL_dtau
   render_projected(...)                        <- rendered_Image_from_Projected_Gaussians_vectorized (:973-1018)
   compute_analytical_jacobians_all_gaussians   <- same name (:705-760), closed form of GetAnalyticalJcobian (:633-703)
   assemble_dL_dtau(...)                        <- the module-level chain-rule loop (:1587-1695)
@@ -20,7 +25,9 @@ _F, _D = torch.float32, torch.float64
 
 
 def _dev(x, dtype, device):
-    return torch.as_tensor(np.ascontiguousarray(x) if isinstance(x, np.ndarray) else x, dtype=dtype, device=device).contiguous()
+    if torch.is_tensor(x):
+        return x.to(device=device, dtype=dtype).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(x), dtype=dtype, device=device).contiguous()
 
 
 def l1_seeds(rendered_color, rendered_depth, gt_color, gt_depth, mask):
@@ -31,9 +38,56 @@ def l1_seeds(rendered_color, rendered_depth, gt_color, gt_depth, mask):
     return gc, gd
 
 
-def compute_gradients_2D(means_2D, covs_2D, colors, depths, alphas, grad_color, grad_depth, device="cuda:0"):
+def project_and_sort(means3D, cov3D6, shs, cam, sh_degree=3, device="cuda:0"):
+    """World-frame Gaussians + camera -> the depth-sorted projected Gaussians the NumPy path works on, all on the device
+    (fp64 arithmetic on the fp32 inputs, like the reference's Python floats; NO z <= 0.2 cull, global STABLE depth order):
+    dict(order [N] int32, mean_2D [N,2], cov_2D [N,2,2], color [N,3], color_raw [N,3], depth [N]) -- every array but `order`
+    in sorted order, fp64.  `cam`: mapping with viewmatrix / projmatrix (the rasteriser's transposed 4x4s), campos, fx, fy, W, H."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    m3, c6, sh = _dev(means3D, _F, dev), _dev(cov3D6, _F, dev), _dev(shs, _F, dev)
+    vm, pm, cp = _dev(cam["viewmatrix"], _F, dev).reshape(16), _dev(cam["projmatrix"], _F, dev).reshape(16), _dev(cam["campos"], _F, dev)
+    N, M = m3.shape[0], sh.shape[1]
+    out = dict(order=torch.empty((N,), dtype=torch.int32, device=dev), mean_2D=torch.empty((N, 2), dtype=_D, device=dev),
+               cov_2D=torch.empty((N, 2, 2), dtype=_D, device=dev), color=torch.empty((N, 3), dtype=_D, device=dev),
+               color_raw=torch.empty((N, 3), dtype=_D, device=dev), depth=torch.empty((N,), dtype=_D, device=dev))
+    ws = torch.empty(lib.gsaj_dense_project_workspace_bytes(N), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gsaj_dense_project(N, M, int(sh_degree), int(cam["W"]), int(cam["H"]), m3.data_ptr(), c6.data_ptr(),
+                                          sh.data_ptr(), vm.data_ptr(), pm.data_ptr(), cp.data_ptr(), float(cam["fx"]),
+                                          float(cam["fy"]), out["order"].data_ptr(), out["mean_2D"].data_ptr(),
+                                          out["cov_2D"].data_ptr(), out["color"].data_ptr(), out["color_raw"].data_ptr(),
+                                          out["depth"].data_ptr(), ws.data_ptr(), _stream(dev)), "gsaj_dense_project")
+    return out
+
+
+def jacobian_test(means3D, cov3D6, opacities, shs, cam, gt_color, gt_depth, mask, sh_degree=3, device="cuda:0"):
+    """The reference's Jacobian test end to end on the device (compare.py:1354-1706, pipeline (C) of SURVEY 3): project and
+    depth-order the Gaussians, composite them densely, seed the summed masked L1 loss against (gt_color [H,W,3], gt_depth
+    [H,W], mask [H,W]), run the dense closed-form backward, the analytical pose Jacobians and the dL/dtau chain rule.
+    -> dict with the four arrays the reference saves to Jacob_test_result/ (grad_mu_I_pixel, grad_Sigma_I_pixel,
+    grad_depth_per_gaussian in depth-sorted row order, fp32; dL_dtau (6,) fp64) + order, rendered colour / depth."""
+    dev = torch.device(device)
+    pr = project_and_sort(means3D, cov3D6, shs, cam, sh_degree, device)
+    order = pr["order"].long()
+    alpha = _dev(opacities, _F, dev).reshape(-1)[order]
+    H, W = int(cam["H"]), int(cam["W"])
+    img, dep = render_projected(pr["mean_2D"], pr["cov_2D"], pr["color"], pr["depth"], alpha, H, W, device)
+    gc, gd = l1_seeds(img, dep, _dev(gt_color, _F, dev), _dev(gt_depth, _F, dev), _dev(mask, torch.bool, dev))
+    g_mu, g_S, g_z, g_c = compute_gradients_2D(pr["mean_2D"], pr["cov_2D"], pr["color"], pr["depth"], alpha, gc, gd, device)
+    N = order.shape[0]
+    mu_h = torch.cat([_dev(means3D, _D, dev), torch.ones((N, 1), dtype=_D, device=dev)], dim=1)
+    dmu, dcov = compute_analytical_jacobians_all_gaussians(mu_h, cov3D6, cam["w2c"], cam["fx"], cam["fy"], W, H, device)
+    tau, parts = assemble_dL_dtau(pr["order"], g_mu, g_S, g_z, g_c, dmu, dcov, means3D, cam["w2c"], cam["campos"], shs, sh_degree,
+                                  device)
+    return dict(grad_mu_I_pixel=g_mu, grad_Sigma_I_pixel=g_S, grad_depth_per_gaussian=g_z, grad_color_per_gaussian=g_c,
+                dL_dtau=tau, dL_dtau_parts=parts, order=pr["order"], rendered_color=img, rendered_depth=dep, projected=pr)
+
+
+def compute_gradients_2D(means_2D, covs_2D, colors, depths, alphas, grad_color, grad_depth, device="cuda:0", naive_guards=False):
     """Depth-sorted projected Gaussians + per-pixel seeds -> (grad_mu_I [N,2], grad_Sigma_I [N,2,2],
-    grad_depth_per_gaussian [N], grad_color_per_gaussian [N,3]), fp32, rows in sorted order."""
+    grad_depth_per_gaussian [N], grad_color_per_gaussian [N,3]), fp32, rows in sorted order.
+    naive_guards=True: edge semantics of the naive per-pixel loop (GSAJ_DENSE_NAIVE_GUARDS)."""
     lib = _lib.load()
     dev = torch.device(device)
     m2, c2 = _dev(means_2D, _F, dev), _dev(covs_2D, _F, dev)
@@ -50,7 +104,7 @@ def compute_gradients_2D(means_2D, covs_2D, colors, depths, alphas, grad_color, 
     with torch.cuda.device(dev):
         _lib.check(lib.gsaj_dense_backward(N, W, H, m2.data_ptr(), c2.data_ptr(), col.data_ptr(), dep.data_ptr(),
                                            op.data_ptr(), gc.data_ptr(), gd.data_ptr(), g_mu.data_ptr(), g_S.data_ptr(),
-                                           g_z.data_ptr(), g_c.data_ptr(), ws.data_ptr(), _stream(dev)),
+                                           g_z.data_ptr(), g_c.data_ptr(), ws.data_ptr(), 1 if naive_guards else 0, _stream(dev)),
                    "gsaj_dense_backward")
     return g_mu, g_S, g_z, g_c
 

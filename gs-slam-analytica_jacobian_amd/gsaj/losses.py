@@ -9,7 +9,7 @@ import torch
 
 from . import _lib
 
-TRACKING, MONOCULAR, NO_EXPOSURE = 1, 2, 4
+TRACKING, MONOCULAR, NO_EXPOSURE, COMPUTE_LOSS = 1, 2, 4, 8
 
 
 def _ptr(t):
@@ -85,3 +85,32 @@ def mapping_loss_seeds(ls, config, image, depth, viewpoint, opacity, initializat
     return ls(flags, alpha, thr, image, depth, opacity, viewpoint.original_image.to(image.device),
               None if mono else _gt_depth(viewpoint, image), None, None if initialization else viewpoint.exposure_a,
               None if initialization else viewpoint.exposure_b)
+
+
+def compute_loss_seeds(ls, color, depth, color_gt, depth_gt, mask, compute_depth_loss=True):
+    """The image part of compute_loss (reference Jacobian_test.py:155-196 = compare.py:144-185) + its gradients: masked L1
+    colour (mean over 3HW) + L1 depth over the pixels with depth_gt > 0 inside the mask (mean over those pixels).  The third
+    term of compute_loss, 10 x the isotropic regulariser, depends on the Gaussians only: IsotropicLoss below."""
+    dgt = depth_gt if depth_gt is None or depth_gt.dim() == 2 else depth_gt.squeeze(0)
+    flags = COMPUTE_LOSS | (0 if compute_depth_loss else MONOCULAR)
+    op = ls.dL_dopacity  # opacity is not an input of compute_loss; any [1,H,W] float buffer satisfies the C ABI's signature
+    return ls(flags, 0.0, 0.0, color, depth, op, color_gt, dgt.contiguous() if compute_depth_loss else None, mask)
+
+
+class IsotropicLoss:
+    """weight * mean |s - mean(s, dim=1)| over the scales [P,C] and its gradient, one launch (C ABI gsaj_isotropic_loss):
+    the regulariser of compute_loss (weight 10) and of the mapping loss (reference utils/slam_backend.py:229-231)."""
+
+    def __init__(self, P, device):
+        self.lib, self.P, self.dev = _lib.load(), int(P), torch.device(device)
+        self.ws = torch.zeros(self.lib.gsaj_isotropic_workspace_bytes(self.P), dtype=torch.uint8, device=self.dev)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=self.dev)
+
+    def __call__(self, scales, weight=10.0, grad_out=None, accumulate=False):
+        if scales.dtype != torch.float32 or not scales.is_contiguous() or scales.shape[0] != self.P:
+            raise _lib.GsajError("scales must be a contiguous float32 [P, C] tensor")
+        g = grad_out if grad_out is not None else torch.empty_like(scales)
+        _lib.check(self.lib.gsaj_isotropic_loss(self.P, int(scales.shape[1]), float(weight), scales.data_ptr(), g.data_ptr(),
+                                                1 if accumulate else 0, self.loss.data_ptr(), self.ws.data_ptr(),
+                                                torch.cuda.current_stream(self.dev).cuda_stream), "gsaj_isotropic_loss")
+        return self.loss[0], g

@@ -196,11 +196,24 @@ int gsaj_profile_end(float *stage_ms /*host [GSAJ_NUM_STAGES]*/, int *stage_laun
 #define GSAJ_LOSS_TRACKING 1    /* opacity weight, grad_mask, opacity > 0.95 depth gate (get_loss_tracking*) */
 #define GSAJ_LOSS_MONOCULAR 2   /* config["Training"]["monocular"]: colour term only */
 #define GSAJ_LOSS_NO_EXPOSURE 4 /* image_ab = image (get_loss_mapping(initialization=True)) */
+#define GSAJ_LOSS_COMPUTE_LOSS 8 /* compute_loss of the verification harness (Jacobian_test.py:155-196, compare.py:144-185):
+                                  * grad_mask = the per-pixel mask; colour = mean over 3HW of |color*mask - gt*mask|; depth = mean
+                                  * over the pixels with gt_depth > 0 inside the mask of |depth - gt|; loss = their plain sum
+                                  * (alpha, rgb_boundary_threshold, exposure ignored; with MONOCULAR: colour term only).  The
+                                  * 10 x isotropic term of compute_loss is per Gaussian: gsaj_isotropic_loss. */
 size_t gsaj_loss_workspace_bytes(int W, int H);
 int gsaj_loss_seeds(int W, int H, int flags, float alpha, float rgb_boundary_threshold, const float *color,
                     const float *depth, const float *opacity, const float *gt_color, const float *gt_depth,
                     const uint8_t *grad_mask, const float *exposure_a, const float *exposure_b, float *dL_dcolor,
                     float *dL_ddepth, float *dL_dopacity, float *out_scalars, void *loss_ws, void *stream);
+
+/* weight * mean |s_ij - mean_j(s_i.)| over scales [P,C] (C = 1..3) -> out_loss[0] (device), and its gradient into dL_dscales
+ * [P,C] (may be NULL; accumulate != 0: added to what is there): the isotropic regulariser of compute_loss (weight 10,
+ * Jacobian_test.py:169-171) and of the mapping loss (slam_backend.py:229-231).  iso_ws: gsaj_isotropic_workspace_bytes(P),
+ * ZEROED ONCE by the caller when allocated.  Deterministic. */
+size_t gsaj_isotropic_workspace_bytes(int P);
+int gsaj_isotropic_loss(int P, int C, float weight, const float *scales, float *dL_dscales, int accumulate, float *out_loss,
+                        void *iso_ws, void *stream);
 
 /* ---- tracking pose step on the device -------------------------------------------
  * One launch = torch.optim.Adam.step() on (cam_trans_delta, cam_rot_delta, exposure_a, exposure_b) as set up in
@@ -233,10 +246,27 @@ size_t gsaj_dense_workspace_bytes(int N, int W, int H);
 /* N depth-sorted Gaussians: means2D [N,2] (pixels), covs2D [N,2,2], colors [N,3], depths [N], opac [N];
  * per-pixel seeds seed_color [H,W,3], seed_depth [H,W]  ->
  * grad_mu [N,2], grad_Sigma [N,2,2], grad_depth [N], grad_color [N,3]. */
+/* flags: GSAJ_DENSE_NAIVE_GUARDS selects the edge semantics of the naive per-pixel loop
+ * (Loss_Derivative_wrt_mu_and_cov.py:3-118 = compare.py:1050-1169) instead of the vectorised golden producer's (:1311): where
+ * alpha_i >= 0.999 the suffix term is dropped rather than divided by 1.0, and an entry with abs(alpha_i) < 1e-8 adds nothing to
+ * grad_mu / grad_Sigma. */
+#define GSAJ_DENSE_NAIVE_GUARDS 1
 int gsaj_dense_backward(int N, int W, int H, const float *means2D, const float *covs2D, const float *colors,
                         const float *depths, const float *opac, const float *seed_color, const float *seed_depth,
                         float *grad_mu, float *grad_Sigma, float *grad_depth, float *grad_color,
-                        void *dense_ws, void *stream);
+                        void *dense_ws, int flags, void *stream);
+/* Front end of the NumPy path (GetImagePlaneMeanAndCovs + compute_cov2d + ndc2Pix + compute_colors_from_sh +
+ * OrderGaussiansByDepth, compare.py:854-971, 772-852, 535-588, 764-769), fp64 arithmetic on the fp32 inputs like the
+ * reference's Python floats, Appendix A.4 semantics: no z <= 0.2 cull, no tile test, colours clamped below at 0 only, one
+ * global STABLE order by view-space z.  means3D [N,3], cov3D [N,6] (xx,xy,xz,yy,yz,zz), shs [N,sh_coeffs,3]; viewmatrix /
+ * projmatrix as for the rasteriser (W2C^T, (P W2C)^T); campos [3].  Outputs (device): order [N] int32 (order[i] = original
+ * index of sorted position i) and, IN SORTED ORDER, mean2D [N,2] pixels, cov2D [N,2,2] pixels^2 (+0.3 dilation), color [N,3],
+ * color_raw [N,3] (before the clamp; may be NULL), depth [N].  project_ws: gsaj_dense_project_workspace_bytes(N). */
+size_t gsaj_dense_project_workspace_bytes(int N);
+int gsaj_dense_project(int N, int sh_coeffs, int sh_degree, int W, int H, const float *means3D, const float *cov3D,
+                       const float *shs, const float *viewmatrix, const float *projmatrix, const float *campos, double fx,
+                       double fy, int *order, double *mean2D, double *cov2D, double *color, double *color_raw, double *depth,
+                       void *project_ws, void *stream);
 /* Dense forward compositor: out_color [H,W,3], out_depth [H,W]. */
 int gsaj_dense_render(int N, int W, int H, const float *means2D, const float *covs2D, const float *colors,
                       const float *depths, const float *opac, float *out_color, float *out_depth, void *stream);

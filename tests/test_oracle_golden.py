@@ -151,3 +151,34 @@ def test_tiled_oracle_preprocess_vs_reference_substeps(golden_dir, name):
     assert np.allclose(st["depths"][o][vis], g["depth"][vis], rtol=1e-5)
     assert np.allclose(st["rgb"][o][vis], g["color"][vis], rtol=1e-4, atol=1e-5)
     assert np.allclose(st["cov3D"], g["cov3D6"], rtol=1e-4, atol=1e-7)
+
+
+def test_naive_loop_edge_branches_golden(golden_dir):
+    """The naive loop's two edge branches (alpha >= 0.999: suffix term dropped; abs(alpha) < 1e-8: entry skipped) -- they differ
+    from the vectorised producer of the goldens, which divides by 1.0 and never skips."""
+    g = _load(golden_dir, "naive_edge_N5_12x9.npz")
+    order = np.argsort(g["depth"], kind="stable")
+    args = (g["mean_2D"][order], g["cov_2D"][order], g["color"][order], g["depth"][order], g["alpha"][order], g["seed_color"], g["seed_depth"])
+    mu, S = dor.dense_backward(*args, naive_guards=True)[:2]
+    inv = np.argsort(order)
+    m_mu, m_S = np.abs(g["grad_mu"]).max(), np.abs(g["grad_Sigma"]).max()
+    assert np.abs(mu[inv] - g["grad_mu"]).max() < 1.5e-6 * m_mu      # measured 3e-7 (fp32 restatement vs the fp64 loop)
+    assert np.abs(S[inv] - g["grad_Sigma"]).max() < 1.5e-6 * m_S
+    # the fixture does exercise the alpha >= 0.999 branch: the vectorised semantics (divide by 1 instead of dropping the
+    # suffix term) land measurably elsewhere -- by little, because behind a 0.999-opaque entry the suffix sums are < 1e-3
+    mu_v = dor.dense_backward(*args)[0]
+    assert np.abs(mu_v[inv] - g["grad_mu"]).max() > 3e-6 * m_mu
+    assert np.all(mu[inv][3] == 0) and np.all(g["grad_mu"][3] == 0)  # the 1e-9-opacity entry is skipped entirely
+
+
+def test_dense_render_golden(golden_dir):
+    """rendered_Image_from_Projected_Gaussians_vectorized (compare.py:973-1018): the image the reference hands to imshow."""
+    g = _load(golden_dir, "dense_N15_640x480.npz")
+    r = _load(golden_dir, "dense_render_N15_640x480.npz")
+    o = g["order"]
+    img, _ = dor.dense_render(g["mean_2D"], g["cov_2D"], g["color"], g["depth"], g["opacities"][o, 0], 480, 640)
+    img = np.clip(img, 0.0, 1.0)
+    vmax = float(r["vmax"])
+    assert np.abs(img[::4, ::4] - r["image_sub4"]).max() < 2e-6 * max(vmax, 1.0)
+    assert np.abs(img.astype(np.float64).sum(axis=1) - r["row_sum"]).max() < 1e-5 * np.abs(r["row_sum"]).max()
+    assert np.abs(img.astype(np.float64).sum(axis=0) - r["col_sum"]).max() < 1e-5 * np.abs(r["col_sum"]).max()
