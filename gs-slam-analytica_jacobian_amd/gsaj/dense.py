@@ -129,7 +129,7 @@ def compute_analytical_jacobians_all_gaussians(mu_W_all_homo, gaussian_3D_covs, 
     in NDC units (x 2fx/W, 2fy/H), the Sigma-Jacobian rows in pixel^2 units (compare.py:724-754)."""
     lib = _lib.load()
     dev = torch.device(device)
-    mu = _dev(np.asarray(mu_W_all_homo)[:, :3], _D, dev)
+    mu = _dev(mu_W_all_homo if torch.is_tensor(mu_W_all_homo) else np.asarray(mu_W_all_homo), _D, dev)[:, :3].contiguous()
     cov = _dev(gaussian_3D_covs, _D, dev)
     T = _dev(np.asarray(T_cw, np.float64).reshape(16), _D, dev)
     N = mu.shape[0]
@@ -147,11 +147,11 @@ def assemble_dL_dtau(order, grad_mu, grad_Sigma, grad_depth, grad_color, dmu_all
     lib = _lib.load()
     dev = torch.device(device)
     N = len(order)
-    o = _dev(np.asarray(order, np.int32), torch.int32, dev)
+    o = _dev(order if torch.is_tensor(order) else np.asarray(order, np.int32), torch.int32, dev)
     gm, gS = _dev(grad_mu, _F, dev), _dev(grad_Sigma, _F, dev)
     gz, gc = _dev(grad_depth, _F, dev), _dev(grad_color, _F, dev)
     dmu, dcov = _dev(dmu_all, _D, dev), _dev(dcov_all, _D, dev)
-    mu = _dev(np.asarray(xyz_world)[:, :3], _D, dev)
+    mu = _dev(xyz_world if torch.is_tensor(xyz_world) else np.asarray(xyz_world), _D, dev)[:, :3].contiguous()
     T = _dev(np.asarray(T_cw, np.float64).reshape(16), _D, dev)
     cp = _dev(campos, _D, dev)
     sh = _dev(shs, _D, dev)

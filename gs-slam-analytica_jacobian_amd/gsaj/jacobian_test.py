@@ -73,12 +73,15 @@ def run(model, cam, gt, autograd=True, device="cuda:0", iso_weight=10.0):
         return dict(loss=loss.detach(), grad_tau=torch.cat([view.cam_trans_delta.grad, view.cam_rot_delta.grad]),
                     grad_xyz=model._xyz.grad, grad_scaling=model._scaling.grad / model.get_scaling.detach(),
                     render=pkg["render"].detach(), depth=pkg["depth"].detach())
-    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)  # noqa: E731
+    from utils.camera_utils import Camera
+
     xyz, opac, shs = model.get_xyz.detach().contiguous(), model.get_opacity.detach().contiguous(), model.get_features.detach().contiguous()
     scales, rots = model.get_scaling.detach().contiguous(), model.get_rotation.detach().contiguous()
     P, M, W, H = xyz.shape[0], shs.shape[1], cam["W"], cam["H"]
     ctx = FrameContext(P, W, H, M, dev)
-    view, proj, praw, campos = t(cam["viewmatrix"]), t(cam["projmatrix"]), t(cam["projmatrix_raw"]), t(cam["campos"])
+    c = Camera.from_synthetic(cam, device=device)  # the matrices exactly as render() derives them (camera_utils.py:95-109)
+    view, proj = c.world_view_transform.contiguous(), c.full_proj_transform.contiguous()
+    praw, campos = c.projection_matrix.contiguous(), c.camera_center.contiguous()
     deg = model.active_sh_degree
     ctx.forward(bg, xyz, opac, view, proj, campos, cam["tanfovx"], cam["tanfovy"], sh_degree=deg, shs=shs, scales=scales, rotations=rots)
     ls = LossSeeds(W, H, dev)
