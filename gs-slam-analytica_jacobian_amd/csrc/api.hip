@@ -159,9 +159,10 @@ int gsaj_forward_preprocess_cap(int P, int D, int M, int W, int H, const float *
   p.grid_x = (W + TILE - 1) / TILE; p.grid_y = (H + TILE - 1) / TILE;
   p.capacity = capacity;
   p.sort_cap = (tile_list_capacity > 0 && tile_list_capacity < SORT_CAP) ? tile_list_capacity : SORT_CAP;
+  p.views = 1;
   ImageWS im;
   image_carve(align_base(image_ws), W, H, &im);
-  return launch_preprocess(p, radii ? radii : g.internal_radii, n_touched, g, im, (hipStream_t)stream);
+  return launch_preprocess(p, radii ? radii : g.internal_radii, n_touched, g, im, ViewStrides{0, 0, 0}, (hipStream_t)stream);
 }
 
 int gsaj_forward_num_rendered(int W, int H, const void *image_ws, void *stream, int *num_rendered, int *max_tile_list) {
@@ -234,7 +235,7 @@ int gsaj_forward_render(int P, int R, int max_tile_list, int W, int H, const flo
   int rc;
   if (max_tile_list >= 0 && max_tile_list <= SORT_CAP) {
     // fast path: per-tile lists sorted in LDS
-    if ((rc = launch_tile_binning(P, R, max_tile_list, (flags & GSAJ_FWD_RECORDS_FP16) ? 1 : 0, gx, gy, rad, features, g, b, im, s)) != GSAJ_OK) return rc;
+    if ((rc = launch_tile_binning(P, R, max_tile_list, (flags & GSAJ_FWD_RECORDS_FP16) ? 1 : 0, gx, gy, rad, features, g, b, im, 1, ViewStrides{0, 0, 0}, s)) != GSAJ_OK) return rc;
   } else {
     // a tile list exceeds the LDS sort capacity (or the caller forces it with max_tile_list < 0):
     // global radix sort of (tile << 32 | depth) keys, as the reference does
@@ -242,7 +243,7 @@ int gsaj_forward_render(int P, int R, int max_tile_list, int W, int H, const flo
     if ((rc = launch_sort(R, 32 + (int)higher_msb((uint32_t)(gx * gy)), b, s)) != GSAJ_OK) return rc;
     if ((rc = launch_ranges_and_records(P, R, gx, gy, rad, features, g, b, im, s)) != GSAJ_OK) return rc;
   }
-  return launch_render_forward(W, H, gx, gy, bg, b, im, out_color, out_depth, out_opacity, n_touched, s);
+  return launch_render_forward(P, W, H, gx, gy, bg, b, im, out_color, out_depth, out_opacity, n_touched, 1, ViewStrides{0, 0, 0}, s);
 }
 
 int gsaj_rasterize_forward(int P, int D, int M, const float *bg, int W, int H, const float *means3D, const float *shs,
@@ -298,8 +299,119 @@ int gsaj_rasterize_forward_async(int P, int D, int M, const float *bg, int W, in
   const int *rad = radii ? radii : g.internal_radii;
   const float *features = colors_precomp ? colors_precomp : g.rgb;
   const int sort_cap = (tile_list_capacity > 0 && tile_list_capacity < SORT_CAP) ? tile_list_capacity : SORT_CAP;
-  if ((rc = launch_tile_binning(P, capacity, sort_cap, (flags & GSAJ_FWD_RECORDS_FP16) ? 1 : 0, gx, gy, rad, features, g, b, im, s)) != GSAJ_OK) return rc;
-  return launch_render_forward(W, H, gx, gy, bg, b, im, out_color, out_depth, out_opacity, n_touched, s);
+  if ((rc = launch_tile_binning(P, capacity, sort_cap, (flags & GSAJ_FWD_RECORDS_FP16) ? 1 : 0, gx, gy, rad, features, g, b, im, 1, ViewStrides{0, 0, 0}, s)) != GSAJ_OK) return rc;
+  return launch_render_forward(P, W, H, gx, gy, bg, b, im, out_color, out_depth, out_opacity, n_touched, 1, ViewStrides{0, 0, 0}, s);
+}
+
+// ---- batched multi-view entry points: K views of ONE Gaussian map (a mapping window) --------------------------------
+static int batch_workspaces(int K, int P, int capacity, int W, int H, void *geom_ws, void *binning_ws, size_t binning_ws_bytes,
+                            void *image_ws, GeomWS *g, BinWS *b, ImageWS *im, ViewStrides *vs) {
+  vs->geom = gsaj_geom_workspace_bytes(P);
+  vs->image = gsaj_image_workspace_bytes(W, H);
+  vs->bin = gsaj_binning_workspace_bytes(capacity);
+  if (((uintptr_t)geom_ws | (uintptr_t)binning_ws | (uintptr_t)image_ws) & 255) {
+    gsaj_set_error("batched entry points need 256-byte aligned workspaces");
+    return GSAJ_ERR_INVALID_ARGUMENT;
+  }
+  if (binning_ws_bytes < vs->bin * (size_t)K) {
+    gsaj_set_error("binning workspace smaller than K x gsaj_binning_workspace_bytes(capacity=%d)", capacity);
+    return GSAJ_ERR_WORKSPACE_TOO_SMALL;
+  }
+  geom_carve(reinterpret_cast<char *>(geom_ws), (size_t)P, g);
+  image_carve(reinterpret_cast<char *>(image_ws), W, H, im);
+  bin_carve(reinterpret_cast<char *>(binning_ws), (size_t)capacity, gsaj_sort_temp_bytes(capacity), b);
+  return GSAJ_OK;
+}
+
+int gsaj_rasterize_forward_batch(int K, int P, int D, int M, const float *bg, int W, int H, const float *means3D, const float *shs,
+                                 const float *colors_precomp, const float *opacities, const float *scales, float scale_modifier,
+                                 const float *rotations, const float *cov3D_precomp, const float *viewmatrices,
+                                 const float *projmatrices, const float *campos, float tanfovx, float tanfovy, int prefiltered,
+                                 float *out_color, float *out_depth, float *out_opacity, int *radii, int *n_touched, void *geom_ws,
+                                 void *binning_ws, size_t binning_ws_bytes, int capacity, int tile_list_capacity, void *image_ws,
+                                 int flags, void *stream) {
+  if (K <= 0 || P <= 0 || W <= 0 || H <= 0 || capacity <= 0 || !means3D || !opacities || !viewmatrices || !projmatrices || !bg ||
+      !out_color || !out_depth || !out_opacity || !radii || !n_touched || !geom_ws || !binning_ws || !image_ws) {
+    gsaj_set_error("gsaj_rasterize_forward_batch: invalid argument (K=%d P=%d W=%d H=%d capacity=%d)", K, P, W, H, capacity);
+    return GSAJ_ERR_INVALID_ARGUMENT;
+  }
+  if ((shs == nullptr) == (colors_precomp == nullptr)) {
+    gsaj_set_error("Please provide excatly one of either SHs or precomputed colors!");
+    return GSAJ_ERR_INVALID_ARGUMENT;
+  }
+  if (((scales == nullptr || rotations == nullptr) && cov3D_precomp == nullptr) ||
+      ((scales != nullptr || rotations != nullptr) && cov3D_precomp != nullptr)) {
+    gsaj_set_error("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+    return GSAJ_ERR_INVALID_ARGUMENT;
+  }
+  if (shs && (!campos || M <= 0 || D < 0 || (D + 1) * (D + 1) > M || D > 3)) {
+    gsaj_set_error("gsaj_rasterize_forward_batch: SH degree %d needs %d coefficients, got M=%d", D, (D + 1) * (D + 1), M);
+    return GSAJ_ERR_INVALID_ARGUMENT;
+  }
+  GeomWS g; BinWS b; ImageWS im; ViewStrides vs;
+  int rc = batch_workspaces(K, P, capacity, W, H, geom_ws, binning_ws, binning_ws_bytes, image_ws, &g, &b, &im, &vs);
+  if (rc != GSAJ_OK) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  FwdParams p;
+  p.P = P; p.D = D; p.M = M; p.W = W; p.H = H;
+  p.means3D = means3D; p.shs = shs; p.colors_precomp = colors_precomp; p.opacities = opacities;
+  p.scales = scales; p.rotations = rotations; p.cov3D_precomp = cov3D_precomp;
+  p.viewmatrix = viewmatrices; p.projmatrix = projmatrices; p.campos = campos;
+  p.scale_modifier = scale_modifier; p.tanfovx = tanfovx; p.tanfovy = tanfovy;
+  p.focal_y = H / (2.0f * tanfovy);
+  p.focal_x = W / (2.0f * tanfovx);
+  p.prefiltered = prefiltered;
+  p.grid_x = (W + TILE - 1) / TILE; p.grid_y = (H + TILE - 1) / TILE;
+  p.capacity = capacity;
+  p.sort_cap = (tile_list_capacity > 0 && tile_list_capacity < SORT_CAP) ? tile_list_capacity : SORT_CAP;
+  p.views = K;
+  if ((rc = launch_preprocess(p, radii, n_touched, g, im, vs, s)) != GSAJ_OK) return rc;
+  if ((rc = launch_tile_binning(P, capacity, p.sort_cap, (flags & GSAJ_FWD_RECORDS_FP16) ? 1 : 0, p.grid_x, p.grid_y, radii, nullptr, g,
+                                b, im, K, vs, s)) != GSAJ_OK)
+    return rc;
+  return launch_render_forward(P, W, H, p.grid_x, p.grid_y, bg, b, im, out_color, out_depth, out_opacity, n_touched, K, vs, s);
+}
+
+int gsaj_rasterize_backward_batch(int K, int P, int D, int M, int capacity, const float *bg, int W, int H, const float *means3D,
+                                  const float *shs, const float *colors_precomp, const float *scales, float scale_modifier,
+                                  const float *rotations, const float *cov3D_precomp, const float *viewmatrices,
+                                  const float *projmatrices, const float *projmatrix_raw, const float *campos, float tanfovx,
+                                  float tanfovy, const int *radii, void *geom_ws, void *binning_ws, void *image_ws,
+                                  const float *dL_dpix, const float *dL_dpix_depth, float *dL_dmean2D, float *dL_dconic,
+                                  float *dL_dopacity, float *dL_dcolor, float *dL_ddepth, float *dL_dmean3D, float *dL_dcov3D,
+                                  float *dL_dsh, float *dL_dscale, float *dL_drot, float *dL_dtau, float *dL_dtau_sum, void *stream) {
+  if (K <= 0 || P <= 0 || capacity <= 0 || W <= 0 || H <= 0 || !bg || !means3D || !viewmatrices || !projmatrices || !projmatrix_raw ||
+      !radii || !geom_ws || !binning_ws || !image_ws || !dL_dpix || !dL_dpix_depth || !dL_dopacity || !dL_dmean3D || !dL_dcov3D ||
+      !dL_dtau_sum) {
+    gsaj_set_error("gsaj_rasterize_backward_batch: invalid argument");
+    return GSAJ_ERR_INVALID_ARGUMENT;
+  }
+  if ((shs && (!dL_dsh || !campos)) || (scales && (!rotations || !dL_dscale || !dL_drot)) || (!scales && !cov3D_precomp)) {
+    gsaj_set_error("gsaj_rasterize_backward_batch: missing gradient buffer for a provided input");
+    return GSAJ_ERR_INVALID_ARGUMENT;
+  }
+  GeomWS g; BinWS b; ImageWS im; ViewStrides vs;
+  int rc = batch_workspaces(K, P, capacity, W, H, geom_ws, binning_ws, gsaj_binning_workspace_bytes(capacity) * (size_t)K, image_ws,
+                            &g, &b, &im, &vs);
+  if (rc != GSAJ_OK) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+  if ((rc = launch_render_backward(capacity, W, H, gx, gy, bg, b, im, dL_dpix, dL_dpix_depth, K, vs, s)) != GSAJ_OK) return rc;
+  BwdParams p;
+  p.P = P; p.D = D; p.M = M; p.W = W; p.H = H;
+  p.means3D = means3D; p.shs = shs; p.scales = scales; p.rotations = rotations;
+  p.cov3Ds = cov3D_precomp ? cov3D_precomp : g.cov3D;
+  p.viewmatrix = viewmatrices; p.projmatrix = projmatrices; p.projmatrix_raw = projmatrix_raw; p.campos = campos;
+  p.scale_modifier = scale_modifier; p.tanfovx = tanfovx; p.tanfovy = tanfovy;
+  p.focal_y = H / (2.0f * tanfovy);
+  p.focal_x = W / (2.0f * tanfovx);
+  p.grid_x = gx; p.grid_y = gy;
+  p.radii = radii;
+  p.dL_dmean2D = dL_dmean2D; p.dL_dconic = dL_dconic; p.dL_dopacity = dL_dopacity; p.dL_dcolor = dL_dcolor;
+  p.dL_ddepth = dL_ddepth; p.dL_dmean3D = dL_dmean3D; p.dL_dcov3D = dL_dcov3D; p.dL_dsh = dL_dsh;
+  p.dL_dscale = dL_dscale; p.dL_drot = dL_drot; p.dL_dtau = dL_dtau; p.dL_dtau_sum = dL_dtau_sum;
+  (void)colors_precomp;
+  return launch_gaussian_backward_batch(p, K, g, b, im, vs, s);
 }
 
 int gsaj_rasterize_backward(int P, int D, int M, int R, const float *bg, int W, int H, const float *means3D,
@@ -334,7 +446,7 @@ int gsaj_rasterize_backward(int P, int D, int M, int R, const float *bg, int W, 
   bin_carve(align_base(binning_ws), (size_t)R, gsaj_sort_temp_bytes(R), &b);
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
   // every output row is written by the kernels (zeros for culled Gaussians): no memsets
-  int rc = launch_render_backward(R, W, H, gx, gy, bg, b, im, dL_dpix, dL_dpix_depth, s);
+  int rc = launch_render_backward(R, W, H, gx, gy, bg, b, im, dL_dpix, dL_dpix_depth, 1, ViewStrides{0, 0, 0}, s);
   if (rc != GSAJ_OK) return rc;
   BwdParams p;
   p.P = P; p.D = D; p.M = M; p.W = W; p.H = H;

@@ -32,24 +32,30 @@ __device__ __forceinline__ float3 dnormvdv(float3 v, float3 dv) {
   return o;
 }
 
-// SH backward IN PLACE: `sh` holds this Gaussian's coefficients [M][3] on entry and dL/dsh on return (zeros above the
-// active degree); within a band every coefficient is read before the band's gradients overwrite it.  Returns dL/dmean
-// through the view direction.
-__device__ __forceinline__ float3 sh_backward(int deg, int M, float3 pos, float3 campos, float *sh,
+// SH backward.  `sh` holds this Gaussian's coefficients [M][3]; dL/dsh goes to `dL_dsh` (zeros above the active degree).
+// dL_dsh may alias sh (the single-view kernel works in place): within a band every coefficient is read before the band's
+// gradients overwrite it.  Returns dL/dmean through the view direction.
+// WEIGHTS: dL_dsh receives only the M basis weights w_k of this view direction (dL/dsh[k][ch] = w_k * g[ch], g = the colour
+// gradient masked by the clamp flags): the batched kernel sums w_k g[ch] over views itself.
+template <bool WEIGHTS>
+__device__ __forceinline__ float3 sh_backward(int deg, int M, float3 pos, float3 campos, const float *sh, float *dL_dsh,
                                               const uint8_t *__restrict__ clamped, float3 gcol) {
-  float *dL_dsh = sh;
   const float3 dorig = make_float3(pos.x - campos.x, pos.y - campos.y, pos.z - campos.z);
   const float len = sqrtf(dorig.x * dorig.x + dorig.y * dorig.y + dorig.z * dorig.z);
   const float x = dorig.x / len, y = dorig.y / len, z = dorig.z / len;
   const float g[3] = {gcol.x * (clamped[0] ? 0.f : 1.f), gcol.y * (clamped[1] ? 0.f : 1.f), gcol.z * (clamped[2] ? 0.f : 1.f)};
   float dx[3] = {0.f, 0.f, 0.f}, dy[3] = {0.f, 0.f, 0.f}, dz[3] = {0.f, 0.f, 0.f};
 #define SH(k, ch) sh[(k) * 3 + (ch)]
-#define OUT(k, w)                                             \
-  {                                                           \
-    const float _w = (w);                                     \
-    dL_dsh[(k) * 3 + 0] = _w * g[0];                          \
-    dL_dsh[(k) * 3 + 1] = _w * g[1];                          \
-    dL_dsh[(k) * 3 + 2] = _w * g[2];                          \
+#define OUT(k, w)                                                                  \
+  {                                                                                \
+    const float _w = (w);                                                          \
+    if (WEIGHTS) {                                                                 \
+      dL_dsh[(k)] = _w;                                                            \
+    } else {                                                                       \
+      dL_dsh[(k) * 3 + 0] = _w * g[0];                                             \
+      dL_dsh[(k) * 3 + 1] = _w * g[1];                                             \
+      dL_dsh[(k) * 3 + 2] = _w * g[2];                                             \
+    }                                                                              \
   }
   OUT(0, bSH_C0)
   if (deg > 0) {
@@ -91,10 +97,175 @@ __device__ __forceinline__ float3 sh_backward(int deg, int M, float3 pos, float3
   }
 #undef SH
 #undef OUT
-  for (int k = (deg + 1) * (deg + 1) * 3; k < 3 * M; k++) dL_dsh[k] = 0.f;  // coefficients above the active degree
+  if (!WEIGHTS)
+    for (int k = (deg + 1) * (deg + 1) * 3; k < 3 * M; k++) dL_dsh[k] = 0.f;  // coefficients above the active degree
   const float3 ddir = make_float3(dx[0] * g[0] + dx[1] * g[1] + dx[2] * g[2], dy[0] * g[0] + dy[1] * g[1] + dy[2] * g[2],
                                   dz[0] * g[0] + dz[1] * g[1] + dz[2] * g[2]);
   return dnormvdv(dorig, ddir);
+}
+
+// Everything one Gaussian contributes for ONE view, from the reverse compositor's sums (s0, s1, s2 = the 10 partials) to
+// dL/d{mean3D, cov3D, scale, rotation, SH} and the 6 pose components -- shared by the single-view and the batched kernel so
+// that both produce the same bits per view.  p.viewmatrix / projmatrix / campos are that view's.
+struct GaussianGrads {
+  float m2x, m2y, ca, cb, cc, op, dz;
+  float3 col, gm, scale;
+  float4 rot;
+  float cov[6];
+};
+template <bool SH_WEIGHTS>
+__device__ __forceinline__ void gaussian_chain(const BwdParams &p, float3 mean, const float (&c6)[6], float3 sc, float4 q,
+                                               const uint8_t (&cl)[3], float4 s0, float4 s1, float4 s2, const float *sh_row,
+                                               float *dsh_row, bool want_scale_rot, GaussianGrads &o, float (&tau)[6]) {
+  const float g2x = s0.x, g2y = s0.y;           // dL/dmean2D (NDC-scaled)
+  const float gcx = s0.z, gcy = s0.w, gcz = s1.x;  // dL/dconic a, b, c
+  const float gop = s1.y;
+  const float3 gcol = make_float3(s1.z, s1.w, s2.x);
+  const float gz = s2.y;
+  // ---- 2. conic -> cov2D -> cov3D, M = J Rcw, t ----
+  const float *vm = p.viewmatrix;
+  const float fx = p.focal_x, fy = p.focal_y;
+  float3 t = xform4x3(vm, mean);
+  const float3 pC = t;  // un-clamped camera-space point
+  const float limx = 1.3f * p.tanfovx, limy = 1.3f * p.tanfovy;
+  const float txtz = t.x / t.z, tytz = t.y / t.z;
+  t.x = fminf(limx, fmaxf(-limx, txtz)) * t.z;
+  t.y = fminf(limy, fmaxf(-limy, tytz)) * t.z;
+  const float xmul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+  const float ymul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+  const float J00 = fx / t.z, J02 = -(fx * t.x) / (t.z * t.z);
+  const float J11 = fy / t.z, J12 = -(fy * t.y) / (t.z * t.z);
+  float Rc[3][3], M[2][3];
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+#pragma unroll
+    for (int c = 0; c < 3; c++) Rc[r][c] = vm[4 * c + r];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    M[0][k] = Rc[0][k] * J00 + Rc[2][k] * J02;
+    M[1][k] = Rc[1][k] * J11 + Rc[2][k] * J12;
+  }
+  const float V[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+  float MV[2][3];
+#pragma unroll
+  for (int r = 0; r < 2; r++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) MV[r][k] = M[r][0] * V[k][0] + M[r][1] * V[k][1] + M[r][2] * V[k][2];
+  const float a = (MV[0][0] * M[0][0] + MV[0][1] * M[0][1] + MV[0][2] * M[0][2]) + 0.3f;
+  const float b = MV[1][0] * M[0][0] + MV[1][1] * M[0][1] + MV[1][2] * M[0][2];
+  const float c = (MV[1][0] * M[1][0] + MV[1][1] * M[1][1] + MV[1][2] * M[1][2]) + 0.3f;
+  const float denom = a * c - b * b;
+  float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
+  const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+  float gcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (denom2inv != 0.f) {
+    dL_da = denom2inv * (-c * c * gcx + 2 * b * c * gcy + (denom - a * c) * gcz);
+    dL_dc = denom2inv * (-a * a * gcz + 2 * a * b * gcy + (denom - a * c) * gcx);
+    dL_db = denom2inv * 2 * (b * c * gcx - (denom + 2 * b * b) * gcy + a * b * gcz);
+    gcov[0] = (M[0][0] * M[0][0] * dL_da + M[0][0] * M[1][0] * dL_db + M[1][0] * M[1][0] * dL_dc);
+    gcov[3] = (M[0][1] * M[0][1] * dL_da + M[0][1] * M[1][1] * dL_db + M[1][1] * M[1][1] * dL_dc);
+    gcov[5] = (M[0][2] * M[0][2] * dL_da + M[0][2] * M[1][2] * dL_db + M[1][2] * M[1][2] * dL_dc);
+    gcov[1] = 2 * M[0][0] * M[0][1] * dL_da + (M[0][0] * M[1][1] + M[0][1] * M[1][0]) * dL_db + 2 * M[1][0] * M[1][1] * dL_dc;
+    gcov[2] = 2 * M[0][0] * M[0][2] * dL_da + (M[0][0] * M[1][2] + M[0][2] * M[1][0]) * dL_db + 2 * M[1][0] * M[1][2] * dL_dc;
+    gcov[4] = 2 * M[0][2] * M[0][1] * dL_da + (M[0][1] * M[1][2] + M[0][2] * M[1][1]) * dL_db + 2 * M[1][1] * M[1][2] * dL_dc;
+  }
+#pragma unroll
+  for (int k = 0; k < 6; k++) o.cov[k] = gcov[k];
+  float dM[2][3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    dM[0][k] = 2 * MV[0][k] * dL_da + MV[1][k] * dL_db;
+    dM[1][k] = 2 * MV[1][k] * dL_dc + MV[0][k] * dL_db;
+  }
+  const float dJ00 = Rc[0][0] * dM[0][0] + Rc[0][1] * dM[0][1] + Rc[0][2] * dM[0][2];
+  const float dJ02 = Rc[2][0] * dM[0][0] + Rc[2][1] * dM[0][1] + Rc[2][2] * dM[0][2];
+  const float dJ11 = Rc[1][0] * dM[1][0] + Rc[1][1] * dM[1][1] + Rc[1][2] * dM[1][2];
+  const float dJ12 = Rc[2][0] * dM[1][0] + Rc[2][1] * dM[1][1] + Rc[2][2] * dM[1][2];
+  const float tz = 1.f / t.z, tz2 = tz * tz, tz3 = tz2 * tz;
+  float3 gt;
+  gt.x = xmul * -fx * tz2 * dJ02;
+  gt.y = ymul * -fy * tz2 * dJ12;
+  gt.z = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2 * fx * t.x) * tz3 * dJ02 + (2 * fy * t.y) * tz3 * dJ12;
+  // tau: rho += g, theta += t x g (clamped t) + sum_k col_k(Rcw) x dL/dcol_k(Rcw)
+  const float3 txg = cross3(t, gt);
+  tau[0] += gt.x; tau[1] += gt.y; tau[2] += gt.z;
+  tau[3] += txg.x; tau[4] += txg.y; tau[5] += txg.z;
+  float3 gm = make_float3(Rc[0][0] * gt.x + Rc[1][0] * gt.y + Rc[2][0] * gt.z,
+                          Rc[0][1] * gt.x + Rc[1][1] * gt.y + Rc[2][1] * gt.z,
+                          Rc[0][2] * gt.x + Rc[1][2] * gt.y + Rc[2][2] * gt.z);
+  {
+    float3 th = make_float3(0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const float3 ck = make_float3(Rc[0][k], Rc[1][k], Rc[2][k]);
+      const float3 gk = make_float3(J00 * dM[0][k], J11 * dM[1][k], J02 * dM[0][k] + J12 * dM[1][k]);
+      const float3 cr = cross3(ck, gk);
+      th.x += cr.x; th.y += cr.y; th.z += cr.z;
+    }
+    tau[3] += th.x; tau[4] += th.y; tau[5] += th.z;
+  }
+
+  // ---- 3. mean2D -> mean3D, tau ----
+  const float *pj = p.projmatrix;
+  const float4 mh = xform4x4(pj, mean);
+  const float mw = 1.0f / (mh.w + 0.0000001f);
+  const float mul1 = (pj[0] * mean.x + pj[4] * mean.y + pj[8] * mean.z + pj[12]) * mw * mw;
+  const float mul2 = (pj[1] * mean.x + pj[5] * mean.y + pj[9] * mean.z + pj[13]) * mw * mw;
+  gm.x += (pj[0] * mw - pj[3] * mul1) * g2x + (pj[1] * mw - pj[3] * mul2) * g2y;
+  gm.y += (pj[4] * mw - pj[7] * mul1) * g2x + (pj[5] * mw - pj[7] * mul2) * g2y;
+  gm.z += (pj[8] * mw - pj[11] * mul1) * g2x + (pj[9] * mw - pj[11] * mul2) * g2y;
+  {
+    const float alpha_ = 1.0f * mw, beta_ = -mh.x * mw * mw, gamma_ = -mh.y * mw * mw;
+    const float pa = p.projmatrix_raw[0], pb = p.projmatrix_raw[5], pe = p.projmatrix_raw[11];
+    const float3 d1 = make_float3(alpha_ * pa, 0.f, beta_ * pe), d2 = make_float3(0.f, alpha_ * pb, gamma_ * pe);
+    const float3 c1 = cross3(pC, d1), c2 = cross3(pC, d2);
+    tau[0] += g2x * d1.x + g2y * d2.x; tau[1] += g2x * d1.y + g2y * d2.y; tau[2] += g2x * d1.z + g2y * d2.z;
+    tau[3] += g2x * c1.x + g2y * c2.x; tau[4] += g2x * c1.y + g2y * c2.y; tau[5] += g2x * c1.z + g2y * c2.z;
+  }
+  // ---- 4. depth -> mean3D, tau: dz/dtau = [0,0,1, y, -x, 0] ----
+  gm.x += gz * vm[2]; gm.y += gz * vm[6]; gm.z += gz * vm[10];
+  tau[2] += gz;
+  tau[3] += gz * pC.y;
+  tau[4] += gz * -pC.x;
+  // ---- 5. colour -> SH, view direction -> mean3D, tau ----
+  if (p.shs) {
+    const float3 cam = make_float3(p.campos[0], p.campos[1], p.campos[2]);
+    const float3 dmean = sh_backward<SH_WEIGHTS>(p.D, p.M, mean, cam, sh_row, dsh_row, cl, gcol);
+    gm.x += dmean.x; gm.y += dmean.y; gm.z += dmean.z;
+    tau[0] -= dmean.x; tau[1] -= dmean.y; tau[2] -= dmean.z;
+  }
+  o.m2x = g2x; o.m2y = g2y; o.ca = gcx; o.cb = gcy; o.cc = gcz; o.op = gop; o.col = gcol; o.dz = gz; o.gm = gm;
+  // ---- 6. cov3D -> scale, rotation ----
+  if (p.scales && want_scale_rot) {  // (skipped in pose-only mode)
+    const float r = q.x, x = q.y, y = q.z, z = q.w;
+    const float R[3][3] = {{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
+                           {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
+                           {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}};
+    const float s[3] = {p.scale_modifier * sc.x, p.scale_modifier * sc.y, p.scale_modifier * sc.z};
+    const float dS[3][3] = {{gcov[0], 0.5f * gcov[1], 0.5f * gcov[2]},
+                            {0.5f * gcov[1], gcov[3], 0.5f * gcov[4]},
+                            {0.5f * gcov[2], 0.5f * gcov[4], gcov[5]}};
+    float dA[3][3];  // A = S R^T, dL/dA = 2 A dSigma
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int cc = 0; cc < 3; cc++)
+        dA[i][cc] = 2.0f * ((s[i] * R[0][i]) * dS[0][cc] + (s[i] * R[1][i]) * dS[1][cc] + (s[i] * R[2][i]) * dS[2][cc]);
+    o.scale.x = R[0][0] * dA[0][0] + R[1][0] * dA[0][1] + R[2][0] * dA[0][2];
+    o.scale.y = R[0][1] * dA[1][0] + R[1][1] * dA[1][1] + R[2][1] * dA[1][2];
+    o.scale.z = R[0][2] * dA[2][0] + R[1][2] * dA[2][1] + R[2][2] * dA[2][2];
+    float gR[3][3];  // dL/dR[j][i] = s_i dA[i][j]
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++) gR[j][i] = s[i] * dA[i][j];
+    float4 dq;
+    dq.x = 2 * z * (gR[1][0] - gR[0][1]) + 2 * y * (gR[0][2] - gR[2][0]) + 2 * x * (gR[2][1] - gR[1][2]);
+    dq.y = 2 * y * (gR[0][1] + gR[1][0]) + 2 * z * (gR[0][2] + gR[2][0]) + 2 * r * (gR[2][1] - gR[1][2]) - 4 * x * (gR[2][2] + gR[1][1]);
+    dq.z = 2 * x * (gR[0][1] + gR[1][0]) + 2 * r * (gR[0][2] - gR[2][0]) + 2 * z * (gR[2][1] + gR[1][2]) - 4 * y * (gR[2][2] + gR[0][0]);
+    dq.w = 2 * r * (gR[1][0] - gR[0][1]) + 2 * x * (gR[0][2] + gR[2][0]) + 2 * y * (gR[2][1] + gR[1][2]) - 4 * z * (gR[1][1] + gR[0][0]);
+    o.rot = dq;
+  }
 }
 
 // SHW = 3*M as a compile-time constant (0: runtime) -- the staging loops divide by it per element
@@ -214,161 +385,15 @@ __global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g
   TRM(1)
   // every output of this Gaussian stays in registers until the dL/dtau hand-off below has been made:
   // the hand-off drains this wave's outstanding stores (s_waitcnt vmcnt(0)), so the bulk stores come last
-  float o_m2x = 0.f, o_m2y = 0.f, o_ca = 0.f, o_cb = 0.f, o_cc = 0.f, o_op = 0.f, o_dz = 0.f;
-  float3 o_col = make_float3(0.f, 0.f, 0.f), o_gm = make_float3(0.f, 0.f, 0.f), o_scale = make_float3(0.f, 0.f, 0.f);
-  float4 o_rot = make_float4(0.f, 0.f, 0.f, 0.f);
-  float o_cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (vis) {
-    const float g2x = s0.x, g2y = s0.y;           // dL/dmean2D (NDC-scaled)
-    const float gcx = s0.z, gcy = s0.w, gcz = s1.x;  // dL/dconic a, b, c
-    const float gop = s1.y;
-    const float3 gcol = make_float3(s1.z, s1.w, s2.x);
-    const float gz = s2.y;
-    // ---- 2. conic -> cov2D -> cov3D, M = J Rcw, t ----
-    const float *vm = p.viewmatrix;
-    const float fx = p.focal_x, fy = p.focal_y;
-    float3 t = xform4x3(vm, mean);
-    const float3 pC = t;  // un-clamped camera-space point
-    const float limx = 1.3f * p.tanfovx, limy = 1.3f * p.tanfovy;
-    const float txtz = t.x / t.z, tytz = t.y / t.z;
-    t.x = fminf(limx, fmaxf(-limx, txtz)) * t.z;
-    t.y = fminf(limy, fmaxf(-limy, tytz)) * t.z;
-    const float xmul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
-    const float ymul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
-    const float J00 = fx / t.z, J02 = -(fx * t.x) / (t.z * t.z);
-    const float J11 = fy / t.z, J12 = -(fy * t.y) / (t.z * t.z);
-    float Rc[3][3], M[2][3];
+  GaussianGrads o;
+  o.m2x = o.m2y = o.ca = o.cb = o.cc = o.op = o.dz = 0.f;
+  o.col = o.gm = o.scale = make_float3(0.f, 0.f, 0.f);
+  o.rot = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-      for (int c = 0; c < 3; c++) Rc[r][c] = vm[4 * c + r];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      M[0][k] = Rc[0][k] * J00 + Rc[2][k] * J02;
-      M[1][k] = Rc[1][k] * J11 + Rc[2][k] * J12;
-    }
-    const float V[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
-    float MV[2][3];
-#pragma unroll
-    for (int r = 0; r < 2; r++)
-#pragma unroll
-      for (int k = 0; k < 3; k++) MV[r][k] = M[r][0] * V[k][0] + M[r][1] * V[k][1] + M[r][2] * V[k][2];
-    const float a = (MV[0][0] * M[0][0] + MV[0][1] * M[0][1] + MV[0][2] * M[0][2]) + 0.3f;
-    const float b = MV[1][0] * M[0][0] + MV[1][1] * M[0][1] + MV[1][2] * M[0][2];
-    const float c = (MV[1][0] * M[1][0] + MV[1][1] * M[1][1] + MV[1][2] * M[1][2]) + 0.3f;
-    const float denom = a * c - b * b;
-    float dL_da = 0.f, dL_db = 0.f, dL_dc = 0.f;
-    const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
-    float gcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (denom2inv != 0.f) {
-      dL_da = denom2inv * (-c * c * gcx + 2 * b * c * gcy + (denom - a * c) * gcz);
-      dL_dc = denom2inv * (-a * a * gcz + 2 * a * b * gcy + (denom - a * c) * gcx);
-      dL_db = denom2inv * 2 * (b * c * gcx - (denom + 2 * b * b) * gcy + a * b * gcz);
-      gcov[0] = (M[0][0] * M[0][0] * dL_da + M[0][0] * M[1][0] * dL_db + M[1][0] * M[1][0] * dL_dc);
-      gcov[3] = (M[0][1] * M[0][1] * dL_da + M[0][1] * M[1][1] * dL_db + M[1][1] * M[1][1] * dL_dc);
-      gcov[5] = (M[0][2] * M[0][2] * dL_da + M[0][2] * M[1][2] * dL_db + M[1][2] * M[1][2] * dL_dc);
-      gcov[1] = 2 * M[0][0] * M[0][1] * dL_da + (M[0][0] * M[1][1] + M[0][1] * M[1][0]) * dL_db + 2 * M[1][0] * M[1][1] * dL_dc;
-      gcov[2] = 2 * M[0][0] * M[0][2] * dL_da + (M[0][0] * M[1][2] + M[0][2] * M[1][0]) * dL_db + 2 * M[1][0] * M[1][2] * dL_dc;
-      gcov[4] = 2 * M[0][2] * M[0][1] * dL_da + (M[0][1] * M[1][2] + M[0][2] * M[1][1]) * dL_db + 2 * M[1][1] * M[1][2] * dL_dc;
-    }
-#pragma unroll
-    for (int k = 0; k < 6; k++) o_cov[k] = gcov[k];
-    float dM[2][3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      dM[0][k] = 2 * MV[0][k] * dL_da + MV[1][k] * dL_db;
-      dM[1][k] = 2 * MV[1][k] * dL_dc + MV[0][k] * dL_db;
-    }
-    const float dJ00 = Rc[0][0] * dM[0][0] + Rc[0][1] * dM[0][1] + Rc[0][2] * dM[0][2];
-    const float dJ02 = Rc[2][0] * dM[0][0] + Rc[2][1] * dM[0][1] + Rc[2][2] * dM[0][2];
-    const float dJ11 = Rc[1][0] * dM[1][0] + Rc[1][1] * dM[1][1] + Rc[1][2] * dM[1][2];
-    const float dJ12 = Rc[2][0] * dM[1][0] + Rc[2][1] * dM[1][1] + Rc[2][2] * dM[1][2];
-    const float tz = 1.f / t.z, tz2 = tz * tz, tz3 = tz2 * tz;
-    float3 gt;
-    gt.x = xmul * -fx * tz2 * dJ02;
-    gt.y = ymul * -fy * tz2 * dJ12;
-    gt.z = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2 * fx * t.x) * tz3 * dJ02 + (2 * fy * t.y) * tz3 * dJ12;
-    // tau: rho += g, theta += t x g (clamped t) + sum_k col_k(Rcw) x dL/dcol_k(Rcw)
-    const float3 txg = cross3(t, gt);
-    tau[0] += gt.x; tau[1] += gt.y; tau[2] += gt.z;
-    tau[3] += txg.x; tau[4] += txg.y; tau[5] += txg.z;
-    float3 gm = make_float3(Rc[0][0] * gt.x + Rc[1][0] * gt.y + Rc[2][0] * gt.z,
-                            Rc[0][1] * gt.x + Rc[1][1] * gt.y + Rc[2][1] * gt.z,
-                            Rc[0][2] * gt.x + Rc[1][2] * gt.y + Rc[2][2] * gt.z);
-    {
-      float3 th = make_float3(0.f, 0.f, 0.f);
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-        const float3 ck = make_float3(Rc[0][k], Rc[1][k], Rc[2][k]);
-        const float3 gk = make_float3(J00 * dM[0][k], J11 * dM[1][k], J02 * dM[0][k] + J12 * dM[1][k]);
-        const float3 cr = cross3(ck, gk);
-        th.x += cr.x; th.y += cr.y; th.z += cr.z;
-      }
-      tau[3] += th.x; tau[4] += th.y; tau[5] += th.z;
-    }
-
-    // ---- 3. mean2D -> mean3D, tau ----
-    const float *pj = p.projmatrix;
-    const float4 mh = xform4x4(pj, mean);
-    const float mw = 1.0f / (mh.w + 0.0000001f);
-    const float mul1 = (pj[0] * mean.x + pj[4] * mean.y + pj[8] * mean.z + pj[12]) * mw * mw;
-    const float mul2 = (pj[1] * mean.x + pj[5] * mean.y + pj[9] * mean.z + pj[13]) * mw * mw;
-    gm.x += (pj[0] * mw - pj[3] * mul1) * g2x + (pj[1] * mw - pj[3] * mul2) * g2y;
-    gm.y += (pj[4] * mw - pj[7] * mul1) * g2x + (pj[5] * mw - pj[7] * mul2) * g2y;
-    gm.z += (pj[8] * mw - pj[11] * mul1) * g2x + (pj[9] * mw - pj[11] * mul2) * g2y;
-    {
-      const float alpha_ = 1.0f * mw, beta_ = -mh.x * mw * mw, gamma_ = -mh.y * mw * mw;
-      const float pa = p.projmatrix_raw[0], pb = p.projmatrix_raw[5], pe = p.projmatrix_raw[11];
-      const float3 d1 = make_float3(alpha_ * pa, 0.f, beta_ * pe), d2 = make_float3(0.f, alpha_ * pb, gamma_ * pe);
-      const float3 c1 = cross3(pC, d1), c2 = cross3(pC, d2);
-      tau[0] += g2x * d1.x + g2y * d2.x; tau[1] += g2x * d1.y + g2y * d2.y; tau[2] += g2x * d1.z + g2y * d2.z;
-      tau[3] += g2x * c1.x + g2y * c2.x; tau[4] += g2x * c1.y + g2y * c2.y; tau[5] += g2x * c1.z + g2y * c2.z;
-    }
-    // ---- 4. depth -> mean3D, tau: dz/dtau = [0,0,1, y, -x, 0] ----
-    gm.x += gz * vm[2]; gm.y += gz * vm[6]; gm.z += gz * vm[10];
-    tau[2] += gz;
-    tau[3] += gz * pC.y;
-    tau[4] += gz * -pC.x;
-    // ---- 5. colour -> SH, view direction -> mean3D, tau ----
-    if (p.shs) {
-      const float3 cam = make_float3(p.campos[0], p.campos[1], p.campos[2]);
-      const float3 dmean = sh_backward(p.D, p.M, mean, cam, sh_io + tid * shs_stride, cl, gcol);
-      gm.x += dmean.x; gm.y += dmean.y; gm.z += dmean.z;
-      tau[0] -= dmean.x; tau[1] -= dmean.y; tau[2] -= dmean.z;
-    }
-    o_m2x = g2x; o_m2y = g2y; o_ca = gcx; o_cb = gcy; o_cc = gcz; o_op = gop; o_col = gcol; o_dz = gz; o_gm = gm;
-    // ---- 6. cov3D -> scale, rotation ----
-    if (p.scales && p.dL_dscale) {  // (skipped in pose-only mode)
-      const float r = q.x, x = q.y, y = q.z, z = q.w;
-      const float R[3][3] = {{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
-                             {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
-                             {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}};
-      const float s[3] = {p.scale_modifier * sc.x, p.scale_modifier * sc.y, p.scale_modifier * sc.z};
-      const float dS[3][3] = {{gcov[0], 0.5f * gcov[1], 0.5f * gcov[2]},
-                              {0.5f * gcov[1], gcov[3], 0.5f * gcov[4]},
-                              {0.5f * gcov[2], 0.5f * gcov[4], gcov[5]}};
-      float dA[3][3];  // A = S R^T, dL/dA = 2 A dSigma
-#pragma unroll
-      for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int cc = 0; cc < 3; cc++)
-          dA[i][cc] = 2.0f * ((s[i] * R[0][i]) * dS[0][cc] + (s[i] * R[1][i]) * dS[1][cc] + (s[i] * R[2][i]) * dS[2][cc]);
-      o_scale.x = R[0][0] * dA[0][0] + R[1][0] * dA[0][1] + R[2][0] * dA[0][2];
-      o_scale.y = R[0][1] * dA[1][0] + R[1][1] * dA[1][1] + R[2][1] * dA[1][2];
-      o_scale.z = R[0][2] * dA[2][0] + R[1][2] * dA[2][1] + R[2][2] * dA[2][2];
-      float gR[3][3];  // dL/dR[j][i] = s_i dA[i][j]
-#pragma unroll
-      for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++) gR[j][i] = s[i] * dA[i][j];
-      float4 dq;
-      dq.x = 2 * z * (gR[1][0] - gR[0][1]) + 2 * y * (gR[0][2] - gR[2][0]) + 2 * x * (gR[2][1] - gR[1][2]);
-      dq.y = 2 * y * (gR[0][1] + gR[1][0]) + 2 * z * (gR[0][2] + gR[2][0]) + 2 * r * (gR[2][1] - gR[1][2]) - 4 * x * (gR[2][2] + gR[1][1]);
-      dq.z = 2 * x * (gR[0][1] + gR[1][0]) + 2 * r * (gR[0][2] - gR[2][0]) + 2 * z * (gR[2][1] + gR[1][2]) - 4 * y * (gR[2][2] + gR[0][0]);
-      dq.w = 2 * r * (gR[1][0] - gR[0][1]) + 2 * x * (gR[0][2] + gR[2][0]) + 2 * y * (gR[2][1] + gR[1][2]) - 4 * z * (gR[1][1] + gR[0][0]);
-      o_rot = dq;
-    }
-  }
+  for (int k = 0; k < 6; k++) o.cov[k] = 0.f;
+  if (vis)
+    gaussian_chain<false>(p, mean, c6, sc, q, cl, s0, s1, s2, sh_io + tid * shs_stride, sh_io + tid * shs_stride,
+                          p.dL_dscale != nullptr, o, tau);
   TRM(2)
   // ---- 7. wave partial of dL/dtau (fixed butterfly) ----
 #pragma unroll
@@ -425,17 +450,17 @@ __global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g
   // ---- 9. outputs: one row per Gaussian, zeros for culled ones (the reference's binding memsets first) ----
   if (idx < p.P && p.dL_dmean2D) {  // pose-only mode (all per-Gaussian outputs NULL) stores nothing per Gaussian
     const size_t i = (size_t)idx;
-    p.dL_dmean2D[3 * i] = o_m2x; p.dL_dmean2D[3 * i + 1] = o_m2y; p.dL_dmean2D[3 * i + 2] = 0.f;
-    reinterpret_cast<float4 *>(p.dL_dconic)[i] = make_float4(o_ca, o_cb, 0.f, o_cc);
-    p.dL_dopacity[i] = o_op;
-    p.dL_dcolor[3 * i] = o_col.x; p.dL_dcolor[3 * i + 1] = o_col.y; p.dL_dcolor[3 * i + 2] = o_col.z;
-    p.dL_ddepth[i] = o_dz;
-    p.dL_dmean3D[3 * i] = o_gm.x; p.dL_dmean3D[3 * i + 1] = o_gm.y; p.dL_dmean3D[3 * i + 2] = o_gm.z;
+    p.dL_dmean2D[3 * i] = o.m2x; p.dL_dmean2D[3 * i + 1] = o.m2y; p.dL_dmean2D[3 * i + 2] = 0.f;
+    reinterpret_cast<float4 *>(p.dL_dconic)[i] = make_float4(o.ca, o.cb, 0.f, o.cc);
+    p.dL_dopacity[i] = o.op;
+    p.dL_dcolor[3 * i] = o.col.x; p.dL_dcolor[3 * i + 1] = o.col.y; p.dL_dcolor[3 * i + 2] = o.col.z;
+    p.dL_ddepth[i] = o.dz;
+    p.dL_dmean3D[3 * i] = o.gm.x; p.dL_dmean3D[3 * i + 1] = o.gm.y; p.dL_dmean3D[3 * i + 2] = o.gm.z;
 #pragma unroll
-    for (int k = 0; k < 6; k++) p.dL_dcov3D[6 * i + k] = o_cov[k];
+    for (int k = 0; k < 6; k++) p.dL_dcov3D[6 * i + k] = o.cov[k];
     if (p.scales) {
-      p.dL_dscale[3 * i] = o_scale.x; p.dL_dscale[3 * i + 1] = o_scale.y; p.dL_dscale[3 * i + 2] = o_scale.z;
-      reinterpret_cast<float4 *>(p.dL_drot)[i] = o_rot;
+      p.dL_dscale[3 * i] = o.scale.x; p.dL_dscale[3 * i + 1] = o.scale.y; p.dL_dscale[3 * i + 2] = o.scale.z;
+      reinterpret_cast<float4 *>(p.dL_drot)[i] = o.rot;
     }
   }
   if (idx < p.P && p.dL_dtau) {
@@ -478,6 +503,242 @@ int launch_gaussian_backward(const BwdParams &p, const GeomWS &g, const BinWS &b
       case 16: hipLaunchKernelGGL(k_gaussian_bwd<48>, dim3(nblk), dim3(GB_BLOCK), lds, s, p, g, im.counters, b.inst_grad, b.reached); break;
       default: hipLaunchKernelGGL(k_gaussian_bwd<0>, dim3(nblk), dim3(GB_BLOCK), lds, s, p, g, im.counters, b.inst_grad, b.reached); break;
     }
+  }
+  GSAJ_HIP_CHECK(hipGetLastError());
+  return GSAJ_OK;
+}
+
+// ---- batched: K views of one map, per-Gaussian parameter gradients summed over the views IN-KERNEL --------------------
+// A mapping window renders every keyframe against the same Gaussians and back-propagates once, so the per-Gaussian
+// gradients accumulate over keyframes while every keyframe keeps its own dL/dtau (reference utils/slam_backend.py:168-232).
+// One workgroup = 64 Gaussians x NW waves (NW = min(K, 8)), wave w taking views w, w + NW, ...: the Gaussian's SH block is
+// read ONCE for all K views (staged in LDS, shared by the waves), every wave streams its view's instance rows exactly like
+// the single-view kernel and runs the same per-Gaussian chain (gaussian_chain: same bits per view), and the views' results
+// are added into ONE LDS row per Gaussian in VIEW ORDER (the waves take turns) -- fixed order end to end, bit-reproducible.
+// The summed gradients are written once instead of K times; dL/dSH is summed in its factored form w_k(view dir) * g[ch].
+#define GBB_MAX_WAVES 8
+#define GBB_ROWS 128  // instance rows staged per wave per trip
+template <int SHW>
+__global__ __launch_bounds__(GB_BLOCK * GBB_MAX_WAVES) void k_gaussian_bwd_batch(BwdParams p, int K, GeomWS g0, ImageWS im0,
+                                                                                 const float4 *__restrict__ inst_grad0,
+                                                                                 const uint8_t *__restrict__ reached0, ViewStrides vs,
+                                                                                 float *__restrict__ pv_mean2D, float *__restrict__ pv_conic,
+                                                                                 float *__restrict__ pv_color, float *__restrict__ pv_depth,
+                                                                                 float *__restrict__ pv_tau) {
+  constexpr int NACC = 17 + SHW;  // opacity, mean3D 3, cov3D 6, scale 3, rot 4, dL/dSH
+  constexpr int MC = SHW / 3;     // SH coefficients stored
+  constexpr int shs_stride = SHW + 1, mstride = NACC + 1;
+  extern __shared__ float lds_dyn[];  // [64][SHW+1] SH coefficients | [64][NACC+1] sums | NW x GBB_ROWS x 3 float4 row staging
+  __shared__ uint32_t s_ticket;
+  const int tid = threadIdx.x & 63, wave = threadIdx.x >> 6, NW = blockDim.x >> 6;
+  const int idx = blockIdx.x * GB_BLOCK + tid;
+  float *sh_in = lds_dyn;
+  float *meet = lds_dyn + ((GB_BLOCK * shs_stride + 3) & ~3);
+  float4 *rows = reinterpret_cast<float4 *>(meet + ((GB_BLOCK * mstride + 3) & ~3)) + wave * GBB_ROWS * REC_F4;
+  const size_t ii = (size_t)(idx < p.P ? idx : 0);
+  // ---- inputs of this Gaussian: once for all views ----
+  const float3 mean = make_float3(p.means3D[3 * ii], p.means3D[3 * ii + 1], p.means3D[3 * ii + 2]);
+  float c6[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) c6[k] = p.cov3Ds[6 * ii + k];  // (view 0's copy: Sigma = R S^2 R^T does not depend on the view)
+  float3 sc = make_float3(0.f, 0.f, 0.f);
+  float4 q = make_float4(1.f, 0.f, 0.f, 0.f);
+  if (p.scales) {
+    sc = make_float3(p.scales[3 * ii], p.scales[3 * ii + 1], p.scales[3 * ii + 2]);
+    q = reinterpret_cast<const float4 *>(p.rotations)[ii];
+  }
+  if (SHW > 0) {  // coalesced load of the workgroup's contiguous [64][M*3] SH block
+    const size_t base = (size_t)blockIdx.x * GB_BLOCK * SHW;
+    const int count = min(GB_BLOCK, p.P - blockIdx.x * GB_BLOCK) * SHW;
+    for (int e = threadIdx.x; e < count; e += (int)blockDim.x) {
+      const int gi = e / (SHW > 0 ? SHW : 1), k = e - gi * SHW;
+      sh_in[gi * shs_stride + k] = p.shs[base + e];
+    }
+  }
+  for (int e = threadIdx.x; e < GB_BLOCK * mstride; e += (int)blockDim.x) meet[e] = 0.f;
+  __syncthreads();
+  const float *vm0 = p.viewmatrix, *pj0 = p.projmatrix, *cam0 = p.campos;
+  const int *radii0 = p.radii;
+  for (int v0 = 0; v0 < K; v0 += NW) {
+    const int v = v0 + wave;
+    GaussianGrads o;
+    o.m2x = o.m2y = o.ca = o.cb = o.cc = o.op = o.dz = 0.f;
+    o.col = o.gm = o.scale = make_float3(0.f, 0.f, 0.f);
+    o.rot = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 6; k++) o.cov[k] = 0.f;
+    float shw[MC > 0 ? MC : 1];  // SH basis weights of this view's direction
+#pragma unroll
+    for (int k = 0; k < MC; k++) shw[k] = 0.f;
+    float gmask[3] = {0.f, 0.f, 0.f};
+    if (v < K) {
+      const GeomWS g = geom_view(g0, (size_t)v * vs.geom);
+      const float4 *inst_grad = gsaj_shift(inst_grad0, (size_t)v * vs.bin);
+      const uint8_t *reached = gsaj_shift(reached0, (size_t)v * vs.bin);
+      const uint32_t *counters = gsaj_shift(im0.counters, (size_t)v * vs.image);
+      p.viewmatrix = vm0 + 16 * v;
+      p.projmatrix = pj0 + 16 * v;
+      p.campos = cam0 ? cam0 + 3 * v : nullptr;
+      const bool aborted = counters[4] != 0u;  // aborted async frame: contributes nothing
+      const int radius = (idx < p.P && !aborted) ? radii0[(size_t)v * p.P + ii] : 0;
+      const bool vis = radius > 0;
+      const uint32_t cnt = (idx < p.P && !aborted) ? g.tiles_touched[ii] : 0u;
+      const uint32_t endi = (idx < p.P && !aborted) ? g.point_offsets[ii] : 0u;
+      const uint32_t first = endi - cnt;
+      const uint32_t F = (uint32_t)__shfl((int)first, 0);
+      uint32_t E = endi;
+#pragma unroll
+      for (int o2 = 32; o2 > 0; o2 >>= 1) E = max(E, (uint32_t)__shfl_xor((int)E, o2));
+      uint8_t cl[3] = {0, 0, 0};
+      if (SHW > 0) { cl[0] = g.clamped[3 * ii]; cl[1] = g.clamped[3 * ii + 1]; cl[2] = g.clamped[3 * ii + 2]; }
+      // gather this wave's contiguous block of instance rows through LDS, each lane summing its own rows in emission order
+      float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0;
+      for (uint32_t lo = F; lo < E; lo += GBB_ROWS) {
+        const uint32_t hi = min(lo + (uint32_t)GBB_ROWS, E);
+        float4 a[GBB_ROWS / 64][3];
+#pragma unroll
+        for (int w = 0; w < GBB_ROWS / 64; w++) {
+          const uint32_t r = lo + (uint32_t)(w * 64 + tid);
+          a[w][0] = a[w][1] = a[w][2] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (r < hi && reached[r]) {
+            const float4 *src = inst_grad + (size_t)r * REC_F4;
+            a[w][0] = src[0]; a[w][1] = src[1]; a[w][2] = src[2];
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int w = 0; w < GBB_ROWS / 64; w++) {
+          rows[(w * 64 + tid) * REC_F4 + 0] = a[w][0];
+          rows[(w * 64 + tid) * REC_F4 + 1] = a[w][1];
+          rows[(w * 64 + tid) * REC_F4 + 2] = a[w][2];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t ub = max(first, lo), ue = min(first + cnt, hi);
+        for (uint32_t u = ub; u < ue; u++) {
+          const float4 a0 = rows[(u - lo) * REC_F4 + 0], a1 = rows[(u - lo) * REC_F4 + 1], a2 = rows[(u - lo) * REC_F4 + 2];
+          s0.x += a0.x; s0.y += a0.y; s0.z += a0.z; s0.w += a0.w;
+          s1.x += a1.x; s1.y += a1.y; s1.z += a1.z; s1.w += a1.w;
+          s2.x += a2.x; s2.y += a2.y;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (vis) {
+        gaussian_chain<true>(p, mean, c6, sc, q, cl, s0, s1, s2, sh_in + tid * shs_stride, shw, p.scales != nullptr, o, tau);
+        gmask[0] = cl[0] ? 0.f : o.col.x; gmask[1] = cl[1] ? 0.f : o.col.y; gmask[2] = cl[2] ? 0.f : o.col.z;
+      }
+      // per-view outputs
+      if (idx < p.P) {
+        const size_t row = (size_t)v * p.P + ii;
+        if (pv_mean2D) { pv_mean2D[3 * row] = o.m2x; pv_mean2D[3 * row + 1] = o.m2y; pv_mean2D[3 * row + 2] = 0.f; }
+        if (pv_conic) reinterpret_cast<float4 *>(pv_conic)[row] = make_float4(o.ca, o.cb, 0.f, o.cc);
+        if (pv_color) { pv_color[3 * row] = o.col.x; pv_color[3 * row + 1] = o.col.y; pv_color[3 * row + 2] = o.col.z; }
+        if (pv_depth) pv_depth[row] = o.dz;
+        if (pv_tau) {
+#pragma unroll
+          for (int k = 0; k < 6; k++) pv_tau[6 * row + k] = tau[k];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 6; k++) {  // wave partial of this view's dL/dtau (same butterfly as the single-view kernel)
+        float t = tau[k];
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) t += __shfl_xor(t, o2);
+        if (tid == 0) __hip_atomic_store(&g.tau_partials[(size_t)blockIdx.x * 8 + k], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    // ---- the views of this round are added to the Gaussian's LDS row in view order: the waves take turns ----
+    for (int w = 0; w < NW; w++) {
+      if (wave == w && v < K) {
+        float *m = meet + tid * mstride;
+        m[0] += o.op;
+        m[1] += o.gm.x; m[2] += o.gm.y; m[3] += o.gm.z;
+#pragma unroll
+        for (int k = 0; k < 6; k++) m[4 + k] += o.cov[k];
+        m[10] += o.scale.x; m[11] += o.scale.y; m[12] += o.scale.z;
+        m[13] += o.rot.x; m[14] += o.rot.y; m[15] += o.rot.z; m[16] += o.rot.w;
+#pragma unroll
+        for (int k = 0; k < MC; k++) {
+          m[17 + 3 * k] += shw[k] * gmask[0];
+          m[17 + 3 * k + 1] += shw[k] * gmask[1];
+          m[17 + 3 * k + 2] += shw[k] * gmask[2];
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // ---- dL/dtau: the last workgroup to arrive sums every view's partials in workgroup order (fp64) ----
+  if (threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_ticket = __hip_atomic_fetch_add(&im0.counters[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (s_ticket == gridDim.x - 1 && p.dL_dtau_sum) {
+    const int nblk = (int)gridDim.x;
+    for (int v = wave; v < K; v += NW) {
+      const float *tp = gsaj_shift(g0.tau_partials, (size_t)v * vs.geom);
+      double a6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      for (int i = tid; i < nblk; i += 64)
+#pragma unroll
+        for (int k = 0; k < 6; k++) a6[k] += (double)__hip_atomic_load(&tp[(size_t)i * 8 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        double t = a6[k];
+#pragma unroll
+        for (int o2 = 32; o2 > 0; o2 >>= 1) t += __shfl_xor(t, o2);
+        if (tid == 0) p.dL_dtau_sum[6 * v + k] = (float)t;
+      }
+    }
+    if (threadIdx.x == 0) im0.counters[3] = 0u;
+  }
+  // ---- outputs, once per Gaussian ----
+  if (wave == 0 && idx < p.P) {
+    const float *m = meet + tid * mstride;
+    const size_t i = (size_t)idx;
+    p.dL_dopacity[i] = m[0];
+    p.dL_dmean3D[3 * i] = m[1]; p.dL_dmean3D[3 * i + 1] = m[2]; p.dL_dmean3D[3 * i + 2] = m[3];
+#pragma unroll
+    for (int k = 0; k < 6; k++) p.dL_dcov3D[6 * i + k] = m[4 + k];
+    if (p.scales) {
+      p.dL_dscale[3 * i] = m[10]; p.dL_dscale[3 * i + 1] = m[11]; p.dL_dscale[3 * i + 2] = m[12];
+      reinterpret_cast<float4 *>(p.dL_drot)[i] = make_float4(m[13], m[14], m[15], m[16]);
+    }
+  }
+  if (SHW > 0 && p.dL_dsh) {  // coalesced store of the [64][M*3] block (coefficients above the active degree stay zero)
+    const size_t base = (size_t)blockIdx.x * GB_BLOCK * SHW;
+    const int count = min(GB_BLOCK, p.P - blockIdx.x * GB_BLOCK) * SHW;
+    for (int e = threadIdx.x; e < count; e += (int)blockDim.x) {
+      const int gi = e / (SHW > 0 ? SHW : 1), k = e - gi * SHW;
+      p.dL_dsh[base + e] = meet[gi * mstride + 17 + k];
+    }
+  }
+}
+
+template <int SHW>
+static void launch_gbb(const BwdParams &p, int K, const GeomWS &g, const BinWS &b, const ImageWS &im, ViewStrides vs, hipStream_t s) {
+  const int nblk = (p.P + GB_BLOCK - 1) / GB_BLOCK;
+  const int nw = K < GBB_MAX_WAVES ? K : GBB_MAX_WAVES;
+  const size_t sh_floats = ((size_t)GB_BLOCK * (SHW + 1) + 3) & ~(size_t)3;
+  const size_t meet = ((size_t)GB_BLOCK * (17 + SHW + 1) + 3) & ~(size_t)3, stage = (size_t)nw * GBB_ROWS * REC_F4 * 4;
+  const size_t lds = sizeof(float) * (sh_floats + meet + stage);
+  hipLaunchKernelGGL(k_gaussian_bwd_batch<SHW>, dim3(nblk), dim3(GB_BLOCK * nw), lds, s, p, K, g, im, b.inst_grad, b.reached, vs,
+                     p.dL_dmean2D, p.dL_dconic, p.dL_dcolor, p.dL_ddepth, p.dL_dtau);
+}
+
+int launch_gaussian_backward_batch(const BwdParams &p, int K, const GeomWS &g, const BinWS &b, const ImageWS &im, ViewStrides vs,
+                                   hipStream_t s) {
+  GsajProfScope ps(ST_GAUSSIAN_BWD, s);
+  switch (p.shs ? p.M : 0) {
+    case 0: launch_gbb<0>(p, K, g, b, im, vs, s); break;
+    case 1: launch_gbb<3>(p, K, g, b, im, vs, s); break;
+    case 4: launch_gbb<12>(p, K, g, b, im, vs, s); break;
+    case 9: launch_gbb<27>(p, K, g, b, im, vs, s); break;
+    case 16: launch_gbb<48>(p, K, g, b, im, vs, s); break;
+    default:
+      gsaj_set_error("batched backward: SH storage of %d coefficients is not supported (1, 4, 9 or 16)", p.M);
+      return GSAJ_ERR_INVALID_ARGUMENT;
   }
   GSAJ_HIP_CHECK(hipGetLastError());
   return GSAJ_OK;

@@ -122,6 +122,34 @@ struct BinWS {  // reference: BinningState, rasterizer_impl.h:55-66
   size_t sort_temp_bytes;
 };
 
+// ---- batched multi-view launches (gsaj_rasterize_*_batch): K views of ONE Gaussian map -------------------------------
+// Every per-view workspace is one of K consecutive, identically carved blocks; kernels run with gridDim.y = K and shift
+// the view-0 pointers by blockIdx.y * stride bytes (wave-uniform: scalar adds).  Single-view launches pass zero strides.
+struct ViewStrides {
+  size_t geom, image, bin;  // bytes between consecutive views' workspaces
+};
+#ifdef __HIPCC__
+template <typename T>
+__device__ __forceinline__ T *gsaj_shift(T *p, size_t bytes) {
+  return reinterpret_cast<T *>(reinterpret_cast<uintptr_t>(p) + bytes);
+}
+__device__ __forceinline__ GeomWS geom_view(GeomWS g, size_t off) {
+  g.depths = gsaj_shift(g.depths, off); g.means2D = gsaj_shift(g.means2D, off); g.cov3D = gsaj_shift(g.cov3D, off);
+  g.conic_opacity = gsaj_shift(g.conic_opacity, off); g.rgb = gsaj_shift(g.rgb, off); g.clamped = gsaj_shift(g.clamped, off);
+  g.tiles_touched = gsaj_shift(g.tiles_touched, off); g.point_offsets = gsaj_shift(g.point_offsets, off);
+  g.internal_radii = gsaj_shift(g.internal_radii, off); g.block_sums = gsaj_shift(g.block_sums, off);
+  g.tau_partials = gsaj_shift(g.tau_partials, off); g.splat = gsaj_shift(g.splat, off);
+  return g;
+}
+__device__ __forceinline__ ImageWS image_view(ImageWS m, size_t off) {
+  m.final_T = gsaj_shift(m.final_T, off); m.n_contrib = gsaj_shift(m.n_contrib, off); m.ranges = gsaj_shift(m.ranges, off);
+  m.counters = gsaj_shift(m.counters, off); m.tile_count = gsaj_shift(m.tile_count, off);
+  m.tile_cursor = gsaj_shift(m.tile_cursor, off); m.tile_offset = gsaj_shift(m.tile_offset, off);
+  m.sticky = gsaj_shift(m.sticky, off); m.finish_list = gsaj_shift(m.finish_list, off);
+  return m;
+}
+#endif
+
 size_t gsaj_sort_temp_bytes(int R);  // binning.hip
 
 static inline size_t bin_carve(char *base, size_t R, size_t sort_temp_bytes, BinWS *g) {
@@ -174,19 +202,27 @@ struct FwdParams {
   int grid_x, grid_y;
   int capacity;  // > 0: async forward, binning arena holds this many instances
   int sort_cap;  // async forward: longest tile list the caller sized the LDS sort for (0: SORT_CAP)
+  int views;     // gridDim.y of the per-view kernels (1: single view); view v reads viewmatrix + 16 v, projmatrix + 16 v,
+                 // campos + 3 v and writes radii + P v, n_touched + P v
 };
 
-int launch_preprocess(const FwdParams &p, int *radii, int *n_touched, const GeomWS &g, const ImageWS &im, hipStream_t s);
+int launch_preprocess(const FwdParams &p, int *radii, int *n_touched, const GeomWS &g, const ImageWS &im, ViewStrides vs,
+                      hipStream_t s);
+// radii: [views, P]; features: colors_precomp [P,3] shared by every view, or NULL = the view's own SH colours (g.rgb)
 int launch_tile_binning(int P, int R, int sort_cap, int rec16, int grid_x, int grid_y, const int *radii, const float *features, const GeomWS &g,
-                        const BinWS &b, const ImageWS &im, hipStream_t s);
+                        const BinWS &b, const ImageWS &im, int views, ViewStrides vs, hipStream_t s);
 int launch_emit_keys(int P, int grid_x, int grid_y, const int *radii, const GeomWS &g, const BinWS &b, hipStream_t s);
 int launch_sort(int R, int end_bit, const BinWS &b, hipStream_t s);
 int launch_ranges_and_records(int P, int R, int grid_x, int grid_y, const int *radii, const float *features,
                               const GeomWS &g, const BinWS &b, const ImageWS &im, hipStream_t s);
-int launch_render_forward(int W, int H, int grid_x, int grid_y, const float *bg, const BinWS &b, const ImageWS &im,
-                          float *out_color, float *out_depth, float *out_opacity, int *n_touched, hipStream_t s);
+// out_color [views,3,H,W], out_depth / out_opacity [views,1,H,W], n_touched [views,P]
+int launch_render_forward(int P, int W, int H, int grid_x, int grid_y, const float *bg, const BinWS &b, const ImageWS &im,
+                          float *out_color, float *out_depth, float *out_opacity, int *n_touched, int views, ViewStrides vs,
+                          hipStream_t s);
+// dL_dpix [views,3,H,W], dL_dpix_depth [views,1,H,W]
 int launch_render_backward(int R, int W, int H, int grid_x, int grid_y, const float *bg, const BinWS &b,
-                           const ImageWS &im, const float *dL_dpix, const float *dL_dpix_depth, hipStream_t s);
+                           const ImageWS &im, const float *dL_dpix, const float *dL_dpix_depth, int views, ViewStrides vs,
+                           hipStream_t s);
 struct BwdParams {
   int P, D, M, W, H;
   const float *means3D, *shs, *scales, *rotations, *cov3Ds;
@@ -198,6 +234,12 @@ struct BwdParams {
       *dL_drot, *dL_dtau, *dL_dtau_sum;
 };
 int launch_gaussian_backward(const BwdParams &p, const GeomWS &g, const BinWS &b, const ImageWS &im, hipStream_t s);
+// K views of one map: per-Gaussian parameter gradients SUMMED over the views in a fixed order (p.dL_dmean3D, dL_dcov3D,
+// dL_dsh, dL_dscale, dL_drot, dL_dopacity: [P, .]); per-view outputs (any may be NULL): dL_dmean2D [K,P,3], dL_dconic [K,P,4],
+// dL_dcolor [K,P,3], dL_ddepth [K,P], dL_dtau [K,P,6]; dL_dtau_sum [K,6].  p.viewmatrix / projmatrix / campos: [K,.];
+// p.radii [K,P].
+int launch_gaussian_backward_batch(const BwdParams &p, int K, const GeomWS &g, const BinWS &b, const ImageWS &im, ViewStrides vs,
+                                   hipStream_t s);
 int launch_mark_visible(int P, const float *means3D, const float *viewmatrix, uint8_t *present, hipStream_t s);
 
 // ---- small device helpers -------------------------------------------------------------------

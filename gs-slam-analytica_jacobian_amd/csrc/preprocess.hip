@@ -108,9 +108,19 @@ __device__ void frame_scan(int nblk, int tiles, int capacity, int sort_cap, uint
 GSAJ_TRACE_DEFINE(pre)
 
 __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__restrict__ radii, int *__restrict__ n_touched,
-                                                         GeomWS g, ImageWS im) {
+                                                         GeomWS g, ImageWS im, ViewStrides vs) {
   __shared__ uint32_t scan[PRE_BLOCK];
   extern __shared__ uint32_t hist[];  // [tiles] workgroup-local tile histogram (when tiles <= LDS_TILES_MAX)
+  {  // batched launch: blockIdx.y = view (its own camera, workspaces and per-view outputs; the Gaussians are shared)
+    const size_t view = blockIdx.y;
+    g = geom_view(g, view * vs.geom);
+    im = image_view(im, view * vs.image);
+    p.viewmatrix += 16 * view;
+    p.projmatrix += 16 * view;
+    if (p.campos) p.campos += 3 * view;
+    radii += view * (size_t)p.P;
+    n_touched += view * (size_t)p.P;
+  }
   GSAJ_TRACE_BEGIN(pre)
 #ifdef GSAJ_BLOCK_TRACE
   unsigned long long trp_[4] = {0, 0, 0, 0}, trp_t = wall_clock64();
@@ -348,8 +358,16 @@ __device__ void frame_scan(int nblk, int tiles, int capacity, int sort_cap, uint
 GSAJ_TRACE_DEFINE(scat)
 
 __global__ __launch_bounds__(PRE_BLOCK) void k_scatter_instances(int P, int gx, int gy, const int *__restrict__ radii,
-                                                                 GeomWS g, ImageWS im, uint64_t *__restrict__ inst_key) {
+                                                                 GeomWS g, ImageWS im, uint64_t *__restrict__ inst_key,
+                                                                 ViewStrides vs) {
   extern __shared__ uint32_t lds[];  // [2*tiles]: count -> reserved base, fill cursor
+  {
+    const size_t view = blockIdx.y;
+    g = geom_view(g, view * vs.geom);
+    im = image_view(im, view * vs.image);
+    inst_key = gsaj_shift(inst_key, view * vs.bin);
+    radii += view * (size_t)P;
+  }
   if (im.counters[4]) return;  // aborted async frame
   GSAJ_TRACE_BEGIN(scat)
 #ifdef GSAJ_BLOCK_TRACE
@@ -490,7 +508,15 @@ __global__ __launch_bounds__(256) void k_tile_sort_records(int gx, int gy, const
                                                            const float *__restrict__ features, GeomWS g, ImageWS im,
                                                            const uint64_t *__restrict__ inst_key,
                                                            uint32_t *__restrict__ point_list,
-                                                           float4 *__restrict__ records, int cap, int rec16) {
+                                                           float4 *__restrict__ records, int cap, int rec16, ViewStrides vs) {
+  {
+    const size_t view = blockIdx.y;
+    g = geom_view(g, view * vs.geom);
+    im = image_view(im, view * vs.image);
+    inst_key = gsaj_shift(inst_key, view * vs.bin);
+    point_list = gsaj_shift(point_list, view * vs.bin);
+    records = gsaj_shift(records, view * vs.bin);
+  }
   // `cap` keys of dynamic LDS: the host sizes it to the longest tile list (sync path: known exactly; async path: the
   // caller's tile_list_capacity, checked on the device by frame_scan), so short lists do not pay for 32 KB per workgroup
   extern __shared__ uint64_t keys[];
@@ -617,36 +643,50 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_mark_visible(int P, const float *
   present[idx] = pv.z > 0.2f;
 }
 
-int launch_preprocess(const FwdParams &p, int *radii, int *n_touched, const GeomWS &g, const ImageWS &im, hipStream_t s) {
+// zero the frame counters + tile histogram / cursors of every view of a batched launch (one launch instead of K memsets)
+__global__ __launch_bounds__(256) void k_zero_frame_state(uint32_t *__restrict__ counters, size_t words, size_t view_stride) {
+  uint32_t *c = gsaj_shift(counters, blockIdx.y * view_stride);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) c[i] = 0u;
+}
+
+int launch_preprocess(const FwdParams &p, int *radii, int *n_touched, const GeomWS &g, const ImageWS &im, ViewStrides vs,
+                      hipStream_t s) {
   const int nblk = (p.P + PRE_BLOCK - 1) / PRE_BLOCK;
-  GSAJ_HIP_CHECK(hipMemsetAsync(im.counters, 0, im.zero_bytes, s));  // the only memset of a forward
+  const int views = p.views > 0 ? p.views : 1;
+  if (views == 1) {
+    GSAJ_HIP_CHECK(hipMemsetAsync(im.counters, 0, im.zero_bytes, s));  // the only memset of a forward
+  } else {
+    const size_t words = im.zero_bytes / sizeof(uint32_t);
+    hipLaunchKernelGGL(k_zero_frame_state, dim3((unsigned)((words + 1023) / 1024), views), dim3(256), 0, s, im.counters, words,
+                       vs.image);
+  }
   {
     GsajProfScope ps(ST_PREPROCESS, s);
     const int tiles = p.grid_x * p.grid_y;
     const size_t lds = tiles <= LDS_TILES_MAX ? sizeof(uint32_t) * (size_t)tiles : 0;
-    hipLaunchKernelGGL(k_preprocess, dim3(nblk), dim3(PRE_BLOCK), lds, s, p, radii, n_touched, g, im);
+    hipLaunchKernelGGL(k_preprocess, dim3(nblk, views), dim3(PRE_BLOCK), lds, s, p, radii, n_touched, g, im, vs);
   }
   GSAJ_HIP_CHECK(hipGetLastError());
   return GSAJ_OK;
 }
 
 int launch_tile_binning(int P, int R, int sort_cap, int rec16, int grid_x, int grid_y, const int *radii, const float *features,
-                        const GeomWS &g, const BinWS &b, const ImageWS &im, hipStream_t s) {
+                        const GeomWS &g, const BinWS &b, const ImageWS &im, int views, ViewStrides vs, hipStream_t s) {
   (void)R;
   const int nblk = (P + PRE_BLOCK - 1) / PRE_BLOCK;
   {
     GsajProfScope ps(ST_SCATTER, s);
     const int tiles = grid_x * grid_y;
     const size_t lds = tiles <= LDS_TILES_MAX ? 2 * sizeof(uint32_t) * (size_t)tiles : 0;
-    hipLaunchKernelGGL(k_scatter_instances, dim3(nblk), dim3(PRE_BLOCK), lds, s, P, grid_x, grid_y, radii, g, im,
-                       b.keys_unsorted);
+    hipLaunchKernelGGL(k_scatter_instances, dim3(nblk, views), dim3(PRE_BLOCK), lds, s, P, grid_x, grid_y, radii, g, im,
+                       b.keys_unsorted, vs);
   }
   {
     GsajProfScope ps(ST_TILE_SORT, s);
     int cap = 128;
     while (cap < sort_cap && cap < SORT_CAP) cap <<= 1;
-    hipLaunchKernelGGL(k_tile_sort_records, dim3(grid_x * grid_y), dim3(256), sizeof(uint64_t) * (size_t)cap, s, grid_x, grid_y,
-                       radii, features, g, im, b.keys_unsorted, b.point_list, b.records, cap, rec16);
+    hipLaunchKernelGGL(k_tile_sort_records, dim3(grid_x * grid_y, views), dim3(256), sizeof(uint64_t) * (size_t)cap, s, grid_x, grid_y,
+                       radii, features, g, im, b.keys_unsorted, b.point_list, b.records, cap, rec16, vs);
   }
   GSAJ_HIP_CHECK(hipGetLastError());
   return GSAJ_OK;

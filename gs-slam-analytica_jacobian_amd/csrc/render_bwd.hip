@@ -41,14 +41,25 @@
 
 GSAJ_TRACE_DEFINE(bwd)
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_render_bwd(int W, int H, int gx, const uint2 *__restrict__ ranges,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_render_bwd(int W, int H, int gx, ImageWS im,
                                                     const float4 *__restrict__ records, const float *__restrict__ bg,
-                                                    const float *__restrict__ final_T,
-                                                    const uint32_t *__restrict__ n_contrib,
                                                     const float *__restrict__ dL_dpix,
                                                     const float *__restrict__ dL_dpix_depth,
-                                                    float4 *__restrict__ inst_grad, uint8_t *__restrict__ reached, const uint32_t *__restrict__ finish_list,
-                                                    const uint32_t *__restrict__ counters) {
+                                                    float4 *__restrict__ inst_grad, uint8_t *__restrict__ reached, ViewStrides vs) {
+  {  // batched launch: blockIdx.y = view
+    const size_t view = blockIdx.y, HWv = (size_t)H * W;
+    im = image_view(im, view * vs.image);
+    records = gsaj_shift(records, view * vs.bin);
+    inst_grad = gsaj_shift(inst_grad, view * vs.bin);
+    reached = gsaj_shift(reached, view * vs.bin);
+    dL_dpix += view * 3 * HWv;
+    dL_dpix_depth += view * HWv;
+  }
+  const uint2 *__restrict__ ranges = im.ranges;
+  const float *__restrict__ final_T = im.final_T;
+  const uint32_t *__restrict__ n_contrib = im.n_contrib;
+  const uint32_t *__restrict__ finish_list = im.finish_list;
+  const uint32_t *__restrict__ counters = im.counters;
   __shared__ float4 rec[BWD_ROUND * REC_F4];
   __shared__ __attribute__((aligned(16))) float acc[4 * ACC_C * ACC_STRIDE];  // [wave][partial][entry]
   __shared__ float2 wu_all[4 * SLOTS * WU_STRIDE];     // [wave][slot][pixel] (w, u)
@@ -262,12 +273,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 }
 
 int launch_render_backward(int R, int W, int H, int grid_x, int grid_y, const float *bg, const BinWS &b,
-                           const ImageWS &im, const float *dL_dpix, const float *dL_dpix_depth, hipStream_t s) {
+                           const ImageWS &im, const float *dL_dpix, const float *dL_dpix_depth, int views, ViewStrides vs,
+                           hipStream_t s) {
   if (R <= 0) return GSAJ_OK;  // (async callers pass the arena capacity as R)
   {
     GsajProfScope ps(ST_RENDER_BWD, s);
-    hipLaunchKernelGGL(k_render_bwd, dim3(grid_x * grid_y), dim3(256), 0, s, W, H, grid_x, im.ranges, b.records, bg,
-                       im.final_T, im.n_contrib, dL_dpix, dL_dpix_depth, b.inst_grad, b.reached, im.finish_list, im.counters);
+    hipLaunchKernelGGL(k_render_bwd, dim3(grid_x * grid_y, views), dim3(256), 0, s, W, H, grid_x, im, b.records, bg, dL_dpix,
+                       dL_dpix_depth, b.inst_grad, b.reached, vs);
   }
   GSAJ_HIP_CHECK(hipGetLastError());
   return GSAJ_OK;

@@ -21,13 +21,26 @@
 
 GSAJ_TRACE_DEFINE(fwd)
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_render_fwd(int W, int H, int gx, const uint2 *__restrict__ ranges,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_render_fwd(int W, int H, int gx, int P, ImageWS im,
                                                     const float4 *__restrict__ records, const float *__restrict__ bg,
-                                                    float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                                                     float *__restrict__ out_color, float *__restrict__ out_depth,
                                                     float *__restrict__ out_opacity, int *__restrict__ n_touched,
-                                                    uint32_t *__restrict__ counters, uint32_t *__restrict__ finish_list,
-                                                    const uint32_t *__restrict__ point_list) {
+                                                    const uint32_t *__restrict__ point_list, ViewStrides vs) {
+  {  // batched launch: blockIdx.y = view
+    const size_t view = blockIdx.y, HWv = (size_t)H * W;
+    im = image_view(im, view * vs.image);
+    records = gsaj_shift(records, view * vs.bin);
+    point_list = gsaj_shift(point_list, view * vs.bin);
+    out_color += view * 3 * HWv;
+    out_depth += view * HWv;
+    out_opacity += view * HWv;
+    n_touched += view * (size_t)P;
+  }
+  const uint2 *__restrict__ ranges = im.ranges;
+  float *__restrict__ final_T = im.final_T;
+  uint32_t *__restrict__ n_contrib = im.n_contrib;
+  uint32_t *__restrict__ counters = im.counters;
+  uint32_t *__restrict__ finish_list = im.finish_list;
   // Each wave (one 8x8 quadrant) walks the tile list on its own: private 64-record staging area, no
   // workgroup barrier anywhere, so a quadrant never waits for a slower neighbour.  The four waves of a
   // tile read the same records; the repeats are served by L1/L2.
@@ -168,12 +181,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
   GSAJ_TRACE_END(fwd)
 }
 
-int launch_render_forward(int W, int H, int grid_x, int grid_y, const float *bg, const BinWS &b, const ImageWS &im,
-                          float *out_color, float *out_depth, float *out_opacity, int *n_touched, hipStream_t s) {
+int launch_render_forward(int P, int W, int H, int grid_x, int grid_y, const float *bg, const BinWS &b, const ImageWS &im,
+                          float *out_color, float *out_depth, float *out_opacity, int *n_touched, int views, ViewStrides vs,
+                          hipStream_t s) {
   {
     GsajProfScope ps(ST_RENDER_FWD, s);
-    hipLaunchKernelGGL(k_render_fwd, dim3(grid_x * grid_y), dim3(256), 0, s, W, H, grid_x, im.ranges, b.records, bg,
-                     im.final_T, im.n_contrib, out_color, out_depth, out_opacity, n_touched, im.counters, im.finish_list, b.point_list);
+    hipLaunchKernelGGL(k_render_fwd, dim3(grid_x * grid_y, views), dim3(256), 0, s, W, H, grid_x, P, im, b.records, bg, out_color,
+                       out_depth, out_opacity, n_touched, b.point_list, vs);
   }
   GSAJ_HIP_CHECK(hipGetLastError());
   return GSAJ_OK;

@@ -370,3 +370,114 @@ class FrameContext:
         """sum over pixels of n_contrib = Gaussian-pixel interactions of the last forward."""
         dbg = debug_export(self.P, self.R, self.W, self.H, self.geom, self.binning, self.img)  # only n_contrib is used
         return int(dbg["n_contrib"].to(torch.int64).sum().item())
+
+
+class BatchContext:
+    """K views of ONE Gaussian map through the batched C-ABI entry points (gsaj_rasterize_forward_batch / _backward_batch): the
+    mapping window of the reference (utils/slam_backend.py:168-232) in one set of launches.  Per-view outputs: color / depth /
+    opacity [K,.,H,W], radii / n_touched [K,P], g["mean2D"] [K,P,3] (densification reads it per view), g["tau_all"] [K,6];
+    per-Gaussian parameter gradients summed over the K views in-kernel, in the flat bucket of gsaj.keyframe_shard (one
+    all-reduce ships it, tail = the K pose-gradient rows)."""
+
+    def __init__(self, K, P, W, H, M, device, has_scales=True, record_bits=32, per_gaussian_tau=False, grad_slots=1):
+        from .keyframe_shard import bucket_numel, bucket_views
+        lib = _lib.load()
+        self.lib, self.K, self.P, self.W, self.H, self.M, self.dev = lib, int(K), int(P), int(W), int(H), int(M), torch.device(device)
+        self.flags = _fwd_flags(record_bits)
+        f = dict(device=self.dev, dtype=_F32)
+        byte = dict(device=self.dev, dtype=torch.uint8)
+        self.color = torch.zeros((K, 3, H, W), **f)
+        self.depth = torch.zeros((K, 1, H, W), **f)
+        self.opacity = torch.zeros((K, 1, H, W), **f)
+        self.radii = torch.zeros((K, P), device=self.dev, dtype=torch.int32)
+        self.n_touched = torch.zeros((K, P), device=self.dev, dtype=torch.int32)
+        self.geom_stride = lib.gsaj_geom_workspace_bytes(P)
+        self.img_stride = lib.gsaj_image_workspace_bytes(W, H)
+        self.geom = torch.empty(K * self.geom_stride, **byte)
+        self.img = torch.zeros(K * self.img_stride, **byte)  # zeroed once: holds the sticky abort counters
+        self.binning = torch.empty(0, **byte)
+        self.capacity, self.tile_list_capacity, self.bin_stride = 0, 0, 0
+        self.buckets, self.slots = [], []
+        for _ in range(max(1, grad_slots)):
+            bucket = torch.zeros(bucket_numel(P, M, has_scales, K), **f)
+            v = bucket_views(bucket, P, M, has_scales, K)
+            self.buckets.append(bucket)
+            self.slots.append(dict(mean2D=torch.zeros((K, P, 3), **f), opacity=v["opacity"], mean3D=v["mean3D"],
+                                   cov3D=v["cov3D"] if not has_scales else torch.zeros((P, 6), **f), sh=v["sh"].view(P, M, 3),
+                                   scale=v.get("scale"), rot=v.get("rot"), tau=torch.zeros((K, P, 6), **f) if per_gaussian_tau else None,
+                                   tau_all=v["tau_all"]))
+        self.bucket, self.g = self.buckets[0], self.slots[0]
+
+    def _size(self, capacity):
+        self.capacity = int(capacity)
+        self.bin_stride = self.lib.gsaj_binning_workspace_bytes(self.capacity)
+        self.binning = torch.empty(self.K * self.bin_stride, device=self.dev, dtype=torch.uint8)
+
+    def status(self):
+        """Blocking: per view (num_rendered, longest tile list, aborted)."""
+        out, st = [], _stream(self.dev)
+        for v in range(self.K):
+            R, mt = ctypes.c_int(0), ctypes.c_int(0)
+            rc = self.lib.gsaj_forward_num_rendered(self.W, self.H, self.img.data_ptr() + v * self.img_stride, st, ctypes.byref(R), ctypes.byref(mt))
+            if rc not in (0, -3):
+                _lib.check(rc, "gsaj_forward_num_rendered")
+            out.append((R.value, mt.value, rc == -3))
+        return out
+
+    def _launch(self, bg, means3D, opacities, viewmatrices, projmatrices, campos, tanfovx, tanfovy, sh_degree, shs, colors_precomp, scales,
+                rotations, cov3D_precomp, scale_modifier):
+        _lib.check(self.lib.gsaj_rasterize_forward_batch(
+            self.K, self.P, int(sh_degree), self.M, _ptr(bg), self.W, self.H, _ptr(means3D), _ptr(shs), _ptr(colors_precomp),
+            _ptr(opacities), _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrices),
+            _ptr(projmatrices), _ptr(campos), float(tanfovx), float(tanfovy), 0, self.color.data_ptr(), self.depth.data_ptr(),
+            self.opacity.data_ptr(), self.radii.data_ptr(), self.n_touched.data_ptr(), self.geom.data_ptr(), self.binning.data_ptr(),
+            self.binning.numel(), self.capacity, self.tile_list_capacity, self.img.data_ptr(), self.flags, _stream(self.dev)),
+            "gsaj_rasterize_forward_batch")
+
+    def forward(self, bg, means3D, opacities, viewmatrices, projmatrices, campos, tanfovx, tanfovy, sh_degree=0, shs=None,
+                colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, scale_modifier=1.0, sync=True):
+        """viewmatrices / projmatrices [K,4,4] (the rasteriser's transposed matrices), campos [K,3].
+        sync=False: no host round trip (arena from an earlier synchronous call; overflowing views abort on the device).
+        sync=True: the K instance counts are read back; if a view did not fit, the arena grows and the batch is re-run."""
+        a = (bg, means3D, opacities, viewmatrices, projmatrices, campos, tanfovx, tanfovy, sh_degree, shs, colors_precomp, scales,
+             rotations, cov3D_precomp, scale_modifier)
+        if self.capacity == 0:
+            self._size(max(4096, 12 * self.P))
+        self._launch(*a)
+        if not sync:
+            return None
+        st = self.status()
+        if any(ab for _, _, ab in st):
+            self._size(int(1.5 * max(r for r, _, _ in st)) + 1024)
+            self.tile_list_capacity = 0  # the maximum (4096) until the lists are known
+            self.img.zero_()
+            self._launch(*a)
+            st = self.status()
+            if any(ab for _, _, ab in st):
+                raise _lib.GsajError("a view needs a tile list longer than the LDS sort handles (4096): use the single-view entry points")
+        self.tile_list_capacity = min(4096, max(self.tile_list_capacity, 2 * max(m for _, m, _ in st), 256))
+        return st
+
+    def backward(self, bg, means3D, viewmatrices, projmatrices, projmatrix_raw, campos, tanfovx, tanfovy, dL_dcolor, dL_ddepth,
+                 sh_degree=0, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, scale_modifier=1.0, slot=0):
+        g = self.slots[slot]
+        _lib.check(self.lib.gsaj_rasterize_backward_batch(
+            self.K, self.P, int(sh_degree), self.M, self.capacity, _ptr(bg), self.W, self.H, _ptr(means3D), _ptr(shs),
+            _ptr(colors_precomp), _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrices),
+            _ptr(projmatrices), _ptr(projmatrix_raw), _ptr(campos), float(tanfovx), float(tanfovy), self.radii.data_ptr(),
+            self.geom.data_ptr(), self.binning.data_ptr(), self.img.data_ptr(), _ptr(dL_dcolor), _ptr(dL_ddepth),
+            g["mean2D"].data_ptr(), None, g["opacity"].data_ptr(), None, None, g["mean3D"].data_ptr(), g["cov3D"].data_ptr(),
+            _ptr(g["sh"]), _ptr(g["scale"]), _ptr(g["rot"]), _ptr(g["tau"]), g["tau_all"].data_ptr(), _stream(self.dev)),
+            "gsaj_rasterize_backward_batch")
+        return g
+
+    def interactions(self):
+        """sum over views and pixels of n_contrib (Gaussian-pixel interactions of the last forward)."""
+        total = 0
+        for v in range(self.K):
+            n = torch.zeros((self.H, self.W), device=self.dev, dtype=torch.int32)
+            _lib.check(self.lib.gsaj_debug_export(self.P, 0, self.W, self.H, None, None, self.img.data_ptr() + v * self.img_stride,
+                                                  None, None, None, None, None, None, None, None, None, None, n.data_ptr(),
+                                                  _stream(self.dev)), "gsaj_debug_export")
+            total += int(n.to(torch.int64).sum().item())
+        return total

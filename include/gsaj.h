@@ -161,6 +161,43 @@ int gsaj_rasterize_backward(int P, int D, int M, int R, const float *bg, int W, 
                             float *dL_ddepth, float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh,
                             float *dL_dscale, float *dL_drot, float *dL_dtau, float *dL_dtau_sum, void *stream);
 
+/* ---- batched multi-view entry points: K views of ONE Gaussian map ------------------------------------------------
+ * The mapping step of the reference renders every keyframe of the window against the same Gaussians, sums the losses and
+ * back-propagates once: per-Gaussian gradients ACCUMULATE over the keyframes, every keyframe keeps its own dL/dtau
+ * (utils/slam_backend.py:168-232).  These two calls do that for K views in one set of launches (grids x K): the Gaussians
+ * are read once per kernel where the view does not matter, the per-Gaussian parameter gradients are summed over the K views
+ * inside the kernel in view order (deterministic) and written once, and K rows of dL/dtau come out.
+ *
+ * Per-view arrays are K consecutive blocks: viewmatrices / projmatrices [K,16], campos [K,3], out_color [K,3,H,W], out_depth
+ * / out_opacity [K,1,H,W], radii / n_touched [K,P], dL_dpix [K,3,H,W], dL_dpix_depth [K,1,H,W].  All K views share W, H,
+ * tanfov (one camera model) and projmatrix_raw.  Workspaces are K consecutive blocks of gsaj_geom_workspace_bytes(P),
+ * gsaj_image_workspace_bytes(W, H) and gsaj_binning_workspace_bytes(capacity) bytes, 256-byte aligned, the image workspaces
+ * zeroed once by the caller; view v's block can be handed to gsaj_forward_num_rendered / gsaj_forward_aborted_count /
+ * gsaj_debug_export on its own.  Like gsaj_rasterize_forward_async there is NO host synchronisation: `capacity` instances
+ * per view, a view that needs more (or a longer tile list than tile_list_capacity) is aborted on the device, contributes
+ * nothing to the sums, and is reported by gsaj_forward_num_rendered(view block).
+ *
+ * Backward outputs.  Summed over the views: dL_dopacity [P], dL_dmean3D [P,3], dL_dcov3D [P,6], dL_dsh [P,M,3], dL_dscale
+ * [P,3], dL_drot [P,4].  Per view (each may be NULL): dL_dmean2D [K,P,3] (what densification reads as
+ * viewspace_points.grad, gaussian_model.py:767-771), dL_dconic [K,P,2,2], dL_dcolor [K,P,3], dL_ddepth [K,P], dL_dtau [K,P,6];
+ * and dL_dtau_sum [K,6].  SH storage of 1, 4, 9 or 16 coefficients. */
+int gsaj_rasterize_forward_batch(int K, int P, int D, int M, const float *bg, int W, int H, const float *means3D,
+                                 const float *shs, const float *colors_precomp, const float *opacities, const float *scales,
+                                 float scale_modifier, const float *rotations, const float *cov3D_precomp,
+                                 const float *viewmatrices, const float *projmatrices, const float *campos, float tanfovx,
+                                 float tanfovy, int prefiltered, float *out_color, float *out_depth, float *out_opacity,
+                                 int *radii, int *n_touched, void *geom_ws, void *binning_ws, size_t binning_ws_bytes,
+                                 int capacity, int tile_list_capacity, void *image_ws, int flags /* GSAJ_FWD_* */, void *stream);
+int gsaj_rasterize_backward_batch(int K, int P, int D, int M, int capacity, const float *bg, int W, int H,
+                                  const float *means3D, const float *shs, const float *colors_precomp, const float *scales,
+                                  float scale_modifier, const float *rotations, const float *cov3D_precomp,
+                                  const float *viewmatrices, const float *projmatrices, const float *projmatrix_raw,
+                                  const float *campos, float tanfovx, float tanfovy, const int *radii, void *geom_ws,
+                                  void *binning_ws, void *image_ws, const float *dL_dpix, const float *dL_dpix_depth,
+                                  float *dL_dmean2D, float *dL_dconic, float *dL_dopacity, float *dL_dcolor, float *dL_ddepth,
+                                  float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh, float *dL_dscale, float *dL_drot,
+                                  float *dL_dtau, float *dL_dtau_sum, void *stream);
+
 /* ---- frustum test -------------------------------------------------------------------- */
 int gsaj_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix,
                       uint8_t *present /*dev [P]*/, void *stream);

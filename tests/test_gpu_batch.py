@@ -1,0 +1,146 @@
+"""GPU: the batched multi-view entry points (gsaj_rasterize_forward_batch / _backward_batch) -- K views of one Gaussian map, the
+reference's mapping window (utils/slam_backend.py:168-232: every keyframe rendered against the same Gaussians, one backward,
+per-Gaussian gradients accumulated over keyframes, one dL/dtau per keyframe).
+
+Per view the batched launch must give the SAME BITS as the single-view entry points for everything the compositors produce
+(same kernels, gridDim.y = view: images, radii, n_touched, dL/dmean2D) and dL/dtau to fp32 rounding; the summed per-Gaussian
+gradients must equal the fp64 sum of the single-view gradients to fp32 rounding; and against the oracle the
+per-keyframe dL/dtau and the sum hold the tolerances of tests/helpers.py (the single-view path is verified term by term in
+test_gpu_full_size.py)."""
+import numpy as np
+import pytest
+
+import helpers as hp
+from gsaj import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(K, cams, sc, deg, precomp=False, record_bits=32, seed=50):
+    import torch
+    from gsaj.rasterizer import BatchContext, FrameContext
+
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)  # noqa: E731
+    P, W, H = sc["means3D"].shape[0], cams[0]["W"], cams[0]["H"]
+    means, opac = t(sc["means3D"]), t(sc["opacities"])
+    if precomp:
+        rng = np.random.default_rng(99)
+        kw = dict(colors_precomp=t(rng.uniform(0, 1, size=(P, 3))), cov3D_precomp=t(syn.covariance6(sc["scales"], sc["rotations"])))
+        M = 0
+    else:
+        kw = dict(shs=t(sc["shs"]), scales=t(sc["scales"]), rotations=t(sc["rotations"]))
+        M = sc["shs"].shape[1]
+    bg = t(np.array([0.1, 0.2, 0.3]))
+    views = t(np.stack([c["viewmatrix"] for c in cams]))
+    projs = t(np.stack([c["projmatrix"] for c in cams]))
+    cps = t(np.stack([c["campos"] for c in cams]))
+    praw = t(cams[0]["projmatrix_raw"])
+    seeds = [hp.seeds(c, seed=seed + k) for k, c in enumerate(cams)]
+    dLc = t(np.stack([s[0] for s in seeds]))
+    dLd = t(np.stack([s[1] for s in seeds]))
+    bc = BatchContext(K, P, W, H, M, dev, has_scales=not precomp, record_bits=record_bits, per_gaussian_tau=True)
+    st = bc.forward(bg, means, opac, views, projs, cps, cams[0]["tanfovx"], cams[0]["tanfovy"], sh_degree=deg, **kw)
+    g = bc.backward(bg, means, views, projs, praw, cps, cams[0]["tanfovx"], cams[0]["tanfovy"], dLc, dLd, sh_degree=deg, **kw)
+    singles = []
+    for k, c in enumerate(cams):
+        fc = FrameContext(P, W, H, M, dev, has_scales=not precomp, record_bits=record_bits, per_gaussian_tau=True)
+        fc.forward(bg, means, opac, views[k], projs[k], cps[k], c["tanfovx"], c["tanfovy"], sh_degree=deg, **kw)
+        gs = fc.backward(bg, means, views[k], projs[k], praw, cps[k], c["tanfovx"], c["tanfovy"], dLc[k], dLd[k], sh_degree=deg, **kw)
+        singles.append((fc, {n: (x.clone() if torch.is_tensor(x) else x) for n, x in gs.items()}, fc.bucket.clone()))
+    return bc, g, st, singles, (dLc, dLd)
+
+
+def _compare(bc, g, st, singles, precomp):
+    import torch
+
+    K = bc.K
+    for k, (fc, gs, bucket) in enumerate(singles):
+        assert st[k][0] == fc.true_R and not st[k][2]
+        assert torch.equal(bc.color[k], fc.color) and torch.equal(bc.depth[k], fc.depth) and torch.equal(bc.opacity[k], fc.opacity)
+        assert torch.equal(bc.radii[k], fc.radii) and torch.equal(bc.n_touched[k], fc.n_touched)
+        assert torch.equal(g["mean2D"][k], gs["mean2D"]), "per-view dL/dmean2D differs from the single-view kernel"
+        # the per-Gaussian chain is a separate template instantiation in the batched kernel (the compiler may fuse multiply-adds
+        # differently): dL/dtau agrees to fp32 rounding, not bit for bit
+        for a, b in ((g["tau"][k], gs["tau"]), (g["tau_all"][k], gs["tau_sum"])):
+            assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), "per-view dL/dtau differs"
+    names = ["mean3D", "opacity", "cov3D"] if precomp else ["mean3D", "opacity", "sh", "scale", "rot"]
+    for n in names:
+        want = sum(s[1][n].double() for s in singles)
+        e = float((g[n].double() - want).abs().max() / want.abs().max())
+        assert e < 3e-5, (n, e)  # K terms, each within the chain's fp32 rounding (cf. */chain_row in parity_errors.jsonl), summed in view order
+
+
+@pytest.mark.parametrize("K,precomp,bits", [(3, False, 32), (5, True, 32), (8, False, 16), (11, False, 32)])
+def test_batch_equals_single_view_per_view_and_sums(K, precomp, bits):
+    cam0, sc, deg = hp.make("p6000_640x480_sh1")
+    cams = syn.keyframe_cameras(K, W=cam0["W"], H=cam0["H"], fx=cam0["fx"], fy=cam0["fy"], cx=cam0["cx"], cy=cam0["cy"])
+    bc, g, st, singles, _ = _run(K, cams, sc, deg, precomp=precomp, record_bits=bits)
+    _compare(bc, g, st, singles, precomp)
+    # bit-reproducible
+    bc2, g2, _, _, _ = _run(K, cams, sc, deg, precomp=precomp, record_bits=bits)
+    import torch
+    assert torch.equal(bc.bucket, bc2.bucket) and torch.equal(g["mean2D"], g2["mean2D"])
+
+
+def test_batch_cfg4_window_vs_oracle():
+    """BASELINE config 4 on one GPU through the batched entry points: 8 TUM-calibrated keyframes, 100 000 Gaussians SH-3."""
+    from oracle import oracle as orc
+
+    orc.set_threads(16)
+    cams, sc = syn.config_window("cfg4", 8)
+    bc, g, st, singles, (dLc, dLd) = _run(8, cams, sc, 3, seed=40)
+    _compare(bc, g, st, singles, False)
+    sums = {}
+    for k, cam in enumerate(cams):
+        (ref, ost), kw = hp.oracle_forward(cam, sc, 3, bg=(0.1, 0.2, 0.3))
+        assert st[k][0] == ref["num_rendered"]
+        hp.assert_image_close(bc.color[k].cpu().numpy(), ref["color"], hp.IMG_TOL, st=ost, tag="batch/cfg4/kf%d" % k)
+        gref = orc.backward(ost, dLc[k].cpu().numpy(), dLd[k].cpu().numpy(), cam["projmatrix_raw"])
+        em = orc.error_model(ost, dLc[k].cpu().numpy(), dLd[k].cpu().numpy(), hp.BORDER_REL, hp.BORDER_REL_T)
+        tol = hp.GRAD_TOL if not em["border_mask"].any() else hp.GRAD_TOL_FLIPPED
+        assert hp.rel_err(g["tau_all"][k].cpu().numpy(), gref["dL_dtau_sum"]) < tol
+        for n, key in (("mean3D", "dL_dmean3D"), ("sh", "dL_dsh"), ("scale", "dL_dscale"), ("rot", "dL_drot"), ("opacity", "dL_dopacity")):
+            sums[n] = sums.get(n, 0) + gref[key].astype(np.float64)
+    for n, want in sums.items():
+        e = hp.rel_err(g[n].double().cpu().numpy().reshape(want.shape), want)
+        hp._errlog("batch/cfg4/sum/" + n, err=e)
+        assert e < 1e-3, (n, e)
+    orc.set_threads(1)
+
+
+def test_batch_aborted_view_contributes_nothing_and_is_reported():
+    """No host sync in the batched path: a view that does not fit its arena aborts on the device, adds nothing to the sums, and
+    gsaj_forward_num_rendered on that view's workspace block says so; the other views are unaffected."""
+    import torch
+    from gsaj.rasterizer import BatchContext
+
+    cam0, sc, deg = hp.make("p6000_640x480_sh1")
+    K = 4
+    cams = syn.keyframe_cameras(K, W=cam0["W"], H=cam0["H"], fx=cam0["fx"], fy=cam0["fy"], cx=cam0["cx"], cy=cam0["cy"])
+    bc, g, st, singles, (dLc, dLd) = _run(K, cams, sc, deg)
+    Rs = [s[0] for s in st]
+    big = int(np.argmax(Rs))
+    assert Rs[big] > min(Rs) + 8, Rs
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)  # noqa: E731
+    P, M = sc["means3D"].shape[0], sc["shs"].shape[1]
+    b2 = BatchContext(K, P, cam0["W"], cam0["H"], M, dev)
+    b2._size(Rs[big] - 1)  # every view but the largest fits
+    b2.tile_list_capacity = bc.tile_list_capacity
+    args = dict(shs=t(sc["shs"]), scales=t(sc["scales"]), rotations=t(sc["rotations"]))
+    views, projs = t(np.stack([c["viewmatrix"] for c in cams])), t(np.stack([c["projmatrix"] for c in cams]))
+    cps, praw, bg = t(np.stack([c["campos"] for c in cams])), t(cams[0]["projmatrix_raw"]), t(np.array([0.1, 0.2, 0.3]))
+    b2.forward(bg, t(sc["means3D"]), t(sc["opacities"]), views, projs, cps, cam0["tanfovx"], cam0["tanfovy"], sh_degree=deg, sync=False, **args)
+    g2 = b2.backward(bg, t(sc["means3D"]), views, projs, praw, cps, cam0["tanfovx"], cam0["tanfovy"], dLc, dLd, sh_degree=deg, **args)
+    st2 = b2.status()
+    fits = [r <= Rs[big] - 1 for r in Rs]
+    assert [s[2] for s in st2] == [not f for f in fits] and st2[big][0] == Rs[big]
+    want = sum(singles[k][1]["mean3D"].double() for k in range(K) if fits[k])
+    assert float((g2["mean3D"].double() - want).abs().max() / want.abs().max()) < 3e-5
+    for k in range(K):
+        if fits[k]:
+            assert float((g2["tau_all"][k] - singles[k][1]["tau_sum"]).abs().max()) <= 2e-6 * float(singles[k][1]["tau_sum"].abs().max())
+            assert torch.equal(b2.color[k], singles[k][0].color)
+        else:
+            assert float(g2["tau_all"][k].abs().max()) == 0.0
