@@ -1,20 +1,25 @@
 #!/usr/bin/env python3
-"""Benchmark of the hot path: forward splat + analytical-Jacobian backward of one 640x480 frame
+"""Benchmark of the hot path: forward splat + analytical-Jacobian backward at 640x480
 (BASELINE.json metric: Gaussian-pixel interactions / second, fwd + Jacobian).
 
   python bench.py --gpus 1 --steps 20 --warmup 5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-A step = one pass of the hot path over one frame per rank: preprocess -> (tile, depth) sort ->
-composite -> reverse composite -> per-Gaussian backward incl. dL/dtau, all through the C ABI of
-libgsaj_hip.so, with every input already resident in HBM.  For N > 1 every rank owns one keyframe
-of the same (replicated) Gaussian map (weak scaling) and the step ends with the RCCL all-reduce of
-the per-Gaussian gradient bucket and the all-gather of the per-keyframe dL/dtau.
-An interaction = one (pixel, Gaussian) pair the compositor visits: I = sum over pixels of n_contrib
-(SURVEY 8d).  Rank 0 prints ONE JSON line.
+A step = one pass of the hot path over one MAPPING WINDOW per rank: `--views` (default 8) keyframes with DISTINCT cameras
+over one shared Gaussian map -- preprocess -> tile binning -> composite -> reverse composite -> per-Gaussian backward with the
+per-Gaussian gradients summed over the keyframes and one dL/dtau per keyframe -- through the batched C ABI of libgsaj_hip.so
+(gsaj_rasterize_forward_batch / _backward_batch), every input already resident in HBM, no host synchronisation inside the
+timed region.  That is the reference's mapping iteration (utils/slam_backend.py:168-232: window of 8-10 keyframes, one
+backward).  For N > 1 every rank owns its own window of the same (replicated) map (weak scaling) and the step ends with ONE
+RCCL all-reduce of the flat gradient bucket (per-Gaussian grads + the pose-gradient rows), overlapped with the next step.
+An interaction = one (pixel, Gaussian) pair the compositor visits: I = sum over views and pixels of n_contrib.
+Beside it: the same workload one frame at a time through the single-view entry points (`single_stream`, the latency a
+sequential tracking loop sees; the per-kernel roofline numbers of the single-view kernels come from that pass).
+Rank 0 prints ONE JSON line.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -31,26 +36,34 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 FLOP_FWD, FLOP_BWD = 24.0, 87.0  # fp32 flop per interaction (+ 1 exp fwd, 1 exp + 1 rcp bwd)
-PEAK_FP32_TFLOPS = 157.3         # MI355X fp32 vector = fp32 MFMA dense peak (MI355X_MICROARCH.md)
+PEAK_FP32_TFLOPS = 157.3         # MI355X fp32 vector peak (MI355X_MICROARCH.md; equals the fp32 MFMA dense peak)
 PEAK_HBM_GBS = 8000.0
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=480)
-    ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg5"])
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"])
+    ap.add_argument("--views", type=int, default=8, help="keyframes per mapping window (per rank), each with its own camera")
     ap.add_argument("--sh-degree", type=int, default=3)
-    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg (rank 0, N=1)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sync", action="store_true", help="read the instance count back on the host every frame")
-    ap.add_argument("--frames-in-flight", type=int, default=3,
-                    help="independent frames (keyframes of a mapping window) processed concurrently, one HIP stream each")
     ap.add_argument("--records", default="fp32", choices=["fp32", "fp16"],
                     help="storage of the sorted instance records (fp16: conic / opacity / colour as halves, config 5)")
-    ap.add_argument("--sh-coeffs", type=int, default=0, help="experiment: keep only the first N SH coefficients per Gaussian")
     return ap.parse_args()
+
+
+def csrc_hash():
+    """Fingerprint of the kernel sources: committed PMC summaries are only quoted if they were taken from THIS code."""
+    h = hashlib.sha1()
+    d = os.path.join(PKG, "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -73,68 +86,56 @@ def main():
 
     from gsaj import synthetic as syn
     from gsaj import keyframe_shard as ks
-    from gsaj.rasterizer import FrameContext, profile_stages, set_record_format
+    from gsaj.rasterizer import BatchContext, FrameContext, profile_stages
 
-    set_record_format(16 if a.records == "fp16" else 32)
-
+    bits = 16 if a.records == "fp16" else 32
     cam0, sc = syn.config_scene(a.workload)
-    if world > 1:  # one keyframe per rank, on a 0.5 m arc around the cfg camera (cfg4-style window)
-        cam = syn.keyframe_cameras(world, W=cam0["W"], H=cam0["H"], fx=cam0["fx"], fy=cam0["fy"], cx=cam0["cx"],
-                                   cy=cam0["cy"])[rank]
-    else:
-        cam = cam0
-    if a.sh_coeffs:
-        sc["shs"] = np.ascontiguousarray(sc["shs"][:, : a.sh_coeffs])
-    P, W, H = sc["means3D"].shape[0], cam["W"], cam["H"]
+    K = max(1, a.views)
+    # the window of this rank: K of the K * world keyframe cameras on the arc around the configuration's camera
+    ckw = {k: cam0[k] for k in ("W", "H", "fx", "fy", "cx", "cy")}
+    cams = syn.keyframe_cameras(K * world, **ckw)[rank * K:(rank + 1) * K]
+    P, W, H = sc["means3D"].shape[0], cam0["W"], cam0["H"]
     M = sc["shs"].shape[1]
     deg = min(a.sh_degree, int(round(M ** 0.5)) - 1)
     t = lambda x: torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32, device=dev)  # noqa: E731
     means, opac, shs, scales, rots = t(sc["means3D"]), t(sc["opacities"]), t(sc["shs"]), t(sc["scales"]), t(sc["rotations"])
-    view, proj, proj_raw, campos = t(cam["viewmatrix"]), t(cam["projmatrix"]), t(cam["projmatrix_raw"]), t(cam["campos"])
+    views, projs = t(np.stack([c["viewmatrix"] for c in cams])), t(np.stack([c["projmatrix"] for c in cams]))
+    campos, proj_raw = t(np.stack([c["campos"] for c in cams])), t(cam0["projmatrix_raw"])
     bg = torch.zeros(3, device=dev)
     rng = np.random.default_rng(1234 + rank)
-    dLc = t(rng.normal(size=(3, H, W)) / (3 * H * W))  # pixel-gradient seeds, resident in HBM
-    dLd = t(rng.normal(size=(1, H, W)) / (H * W))
-    # two gradient buckets: the all-reduce of step i (RCCL stream) overlaps the kernels of step i+1
-    S = max(1, a.frames_in_flight)
-    ctxs = [FrameContext(P, W, H, M, dev, grad_slots=2 if world > 1 else 1, n_keyframes=world if world > 1 else 0,
-                         keyframe=rank) for _ in range(S)]
-    ctx = ctxs[0]
-    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(S - 1)]
-    pending = [[None, None] for _ in range(S)]
-    counter, seen = [0], [0] * S
+    dLc = t(rng.normal(size=(K, 3, H, W)) / (3 * H * W))  # pixel-gradient seeds of every keyframe, resident in HBM
+    dLd = t(rng.normal(size=(K, 1, H, W)) / (H * W))
+    tx, ty = cam0["tanfovx"], cam0["tanfovy"]
+    geo = dict(sh_degree=deg, shs=shs, scales=scales, rotations=rots)
 
-    def step(single=False):
-        k = 0 if single else counter[0] % S  # frame slot: its own workspaces, gradient buckets and HIP stream
-        n = seen[k]                 # how many frames this slot has processed
-        seen[k] += 1
+    # two gradient buckets: the all-reduce of step i (RCCL stream) overlaps the kernels of step i+1
+    ctx = BatchContext(K, P, W, H, M, dev, record_bits=bits, grad_slots=2 if world > 1 else 1, n_windows=world, window=rank)
+    pending = [None, None]
+    counter = [0]
+
+    def step():
+        n = counter[0]
         counter[0] += 1
         slot = n & 1 if world > 1 else 0
-        c, pend = ctxs[k], pending[k]
-        with torch.cuda.stream(streams[k]):
-            if pend[slot] is not None:
-                pend[slot].wait()  # stream-level: the bucket is about to be overwritten
-                pend[slot] = None
-            # first frame: synchronous (sizes the binning arena); afterwards no host round trip per frame
-            c.forward(bg, means, opac, view, proj, campos, cam["tanfovx"], cam["tanfovy"], sh_degree=deg, shs=shs,
-                      scales=scales, rotations=rots, sync=(n == 0) or a.sync)
-            c.backward(bg, means, view, proj, proj_raw, campos, cam["tanfovx"], cam["tanfovy"], dLc, dLd,
-                       sh_degree=deg, shs=shs, scales=scales, rotations=rots, slot=slot)
-            if world > 1:  # one collective: per-Gaussian grads summed, per-keyframe dL/dtau gathered (bucket tail)
-                pend[slot] = ks.allreduce_gaussian_grads(c.buckets[slot], async_op=True)
+        if pending[slot] is not None:
+            pending[slot].wait()  # stream-level: the bucket is about to be overwritten
+            pending[slot] = None
+        # first window: synchronous (sizes the binning arenas); afterwards no host round trip
+        ctx.forward(bg, means, opac, views, projs, campos, tx, ty, sync=(n == 0), **geo)
+        ctx.backward(bg, means, views, projs, proj_raw, campos, tx, ty, dLc, dLd, slot=slot, **geo)
+        if world > 1:  # one collective: per-Gaussian grads summed over ranks; bucket tail = this rank's pose-gradient rows
+            pending[slot] = ks.allreduce_gaussian_grads(ctx.buckets[slot], async_op=True)
 
     def fence():
-        for k in range(S):
-            with torch.cuda.stream(streams[k]):
-                for i in range(2):
-                    if pending[k][i] is not None:
-                        pending[k][i].wait()
-                        pending[k][i] = None
+        for i in range(2):
+            if pending[i] is not None:
+                pending[i].wait()
+                pending[i] = None
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    a.warmup = max(a.warmup, S)  # every frame slot sizes its binning arena on its first (synchronous) frame
+    a.warmup = max(a.warmup, 2)
     for _ in range(a.warmup):
         step()
     fence()
@@ -144,24 +145,41 @@ def main():
     t_enqueued = time.perf_counter() - t0  # host time to enqueue the K steps (the GPU runs behind it)
     fence()
     elapsed = time.perf_counter() - t0
-    for c in ctxs:
-        R, _ = c.status()  # raises if any asynchronous frame was aborted on the device (arena too small)
+    st = ctx.status()
+    assert not any(ab for _, _, ab in st), "a view was aborted on the device (arena too small): %r" % (st,)
     inter = ctx.interactions()
+    R = sum(r for r, _, _ in st)
 
-    # the same K steps one frame at a time on one stream: per-frame latency as the tracker sees it
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step(single=True)
-    fence()
-    elapsed_single = time.perf_counter() - t0
-
-    # and once more with every kernel bracketed by HIP events on its launch stream
+    # the same steps again with every kernel bracketed by HIP events on its launch stream (outside the timed region)
     fence()
     with profile_stages(max_records=a.steps * 16) as prof:
         for _ in range(a.steps):
-            step(single=True)
-    fence()
+            step()
+        fence()
+
+    # one frame at a time through the single-view entry points: the latency of a sequential tracking loop
+    fc = FrameContext(P, W, H, M, dev, record_bits=bits)
+    n_single = max(a.steps, 20)
+
+    def single(n):
+        k = n % K
+        fc.forward(bg, means, opac, views[k], projs[k], campos[k], tx, ty, sync=(n < K), **geo)
+        fc.backward(bg, means, views[k], projs[k], proj_raw, campos[k], tx, ty, dLc[k], dLd[k], **geo)
+
+    for n in range(K):  # every camera once, synchronously: sizes the arena for the largest view
+        single(n)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for n in range(K, K + n_single):
+        single(n)
+    torch.cuda.synchronize(dev)
+    elapsed_single = time.perf_counter() - t0
+    fc.status()
+    with profile_stages(max_records=n_single * 16) as prof1:
+        for n in range(K, K + n_single):
+            single(n)
+        torch.cuda.synchronize(dev)
+    inter_1 = inter / K  # mean interactions per frame of the window
 
     stats = torch.tensor([elapsed, float(inter), float(R)], dtype=torch.float64, device=dev)
     if world > 1:
@@ -176,99 +194,141 @@ def main():
     if rank == 0:
         ms_step = 1e3 * elapsed / a.steps
         value = inter_total * a.steps / elapsed
-        n = max(prof.launches["render_bwd"], 1)
-        t_bwd = prof.ms["render_bwd"] / n * 1e-3
-        t_fwd = prof.ms["render_fwd"] / max(prof.launches["render_fwd"], 1) * 1e-3
-        t_gb = prof.ms["gaussian_bwd"] / max(prof.launches["gaussian_bwd"], 1) * 1e-3
-        t_pre = prof.ms["preprocess"] / max(prof.launches["preprocess"], 1) * 1e-3
-        pre_bytes = P * ((12 + 4 + 12 + 16 + shf_in(M)) + (4 + 8 + 24 + 16 + 12 + 3 + 4 + 4 + 4 + 48))
-        ach = FLOP_BWD * inter / t_bwd / 1e12 if t_bwd > 0 else 0.0
+
+        def per_launch(p, k):
+            return p.ms[k] / max(p.launches[k], 1) * 1e-3
+
         shf = 3 * M * 4
-        gb_bytes = P * ((12 + 24 + 4 + 16 + 12 + shf + 12 + 16 + 3) + (12 + 16 + 4 + 12 + 4 + 12 + 24 + shf + 12 + 16)) + R * (48 + 4)
+        # algorithmic bytes per launch of the batched kernels (K views), SURVEY 8(d) regime 1
+        pre_bytes = K * P * ((12 + 4 + 12 + 16 + shf) + (4 + 8 + 24 + 16 + 12 + 3 + 4 + 4 + 4 + 48))
+        gb_bytes = P * ((12 + 24 + 12 + 16 + shf) + (12 + 4 + 24 + shf + 12 + 16)) + K * P * (4 + 4 + 4 + 3 + 12) + R * (48 + 1)
+        scat_bytes = K * P * (4 + 8 + 4 + 4 + 4) + R * 8
+        sort_bytes = R * (8 + 4 + (32 if bits == 16 else 48) + 48)
+        t_bwd, t_fwd = per_launch(prof, "render_bwd"), per_launch(prof, "render_fwd")
+        ach = FLOP_BWD * inter / t_bwd / 1e12 if t_bwd > 0 else 0.0
+        pmc = pmc_summary()
+        bwd_pmc = (pmc or {}).get("k_render_bwd", {})
+
+        def hbm(name, stage, nbytes, p=prof):
+            tl = per_launch(p, stage)
+            return {"bound": "hbm", "achieved": nbytes / tl / 1e9 if tl > 0 else 0.0, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": nbytes / tl / 1e9 / PEAK_HBM_GBS if tl > 0 else 0.0, "avg_launch_ms": tl * 1e3, "algorithmic_bytes": nbytes,
+                    "traffic": traffic_of((pmc or {}).get(name))}
+
+        t1_bwd, t1_fwd = per_launch(prof1, "render_bwd"), per_launch(prof1, "render_fwd")
         out = {
             "metric": "Gaussian-pixel interactions/sec (fwd+Jacobian), 640x480",
             "value": value, "unit": "interactions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if a.records == "fp32" else "f32 (records stored as f16)", "data": "synthetic",
-            "config": {"workload": "%s: %d Gaussians (SH degree %d, %d coeffs), %dx%d, forward splat + analytical "
-                                   "Jacobian backward (dL/dmu, dL/dSigma->conic, per-Gaussian grads, dL/dtau)"
-                                   % (a.workload, P, deg, M, W, H),
-                       "interactions_per_frame_rank0": inter, "num_rendered_rank0": R, "frames_in_flight": S,
-                       "parallelism": ("%d independent frames in flight per GPU, one HIP stream each; " % S) + "1 keyframe per GPU; ONE async all-reduce of a %d-float bucket (per-Gaussian grads + per-keyframe dL/dtau rows), overlapped with the next step"
-                                      % ctx.buckets[0].numel() if world > 1 else "single GPU; %d independent frames in flight, one HIP stream each" % S},
-            "roofline": {"bound": "mfma", "kernel": "k_render_bwd", "achieved": ach, "peak": PEAK_FP32_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
-                         "traffic": pmc_traffic("k_render_bwd") if (a.workload == "cfg2" and M == 16) else None,
-                         "traffic_unit": "bytes/launch (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes, "
-                                         "profiles/r01_pmc_hbm_fetch_write_kb.json; algorithmic: %d)" % (R * 96 + W * H * 32),
-                         "note": "fp32 VALU/transcendental-bound reverse compositor: 87 fp32 flop x interactions per "
-                                 "launch / HIP-event launch time; peak = fp32 vector = fp32 MFMA dense peak",
-                         "avg_launch_ms": t_bwd * 1e3},
+            "config": {"workload": "%s: %d Gaussians (SH degree %d, %d coeffs), %dx%d; one step = one mapping window of %d keyframes with "
+                                   "distinct cameras: forward splat + analytical-Jacobian backward (dL/dmu, dL/dSigma->conic, per-Gaussian "
+                                   "grads summed over the window, one dL/dtau per keyframe)" % (a.workload, P, deg, M, W, H, K),
+                       "views_per_step": K, "ms_per_frame": ms_step / K, "interactions_per_step_rank0": inter, "num_rendered_per_step_rank0": R,
+                       "parallelism": ("1 window of %d keyframes per GPU; ONE async all-reduce of a %d-float bucket per step (per-Gaussian grads "
+                                       "+ pose-gradient rows), overlapped with the next step" % (K, ctx.buckets[0].numel())) if world > 1
+                       else "single GPU, one HIP stream, batched launches (grids x %d views)" % K},
+            "roofline": {"bound": "valu", "kernel": "k_render_bwd", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / PEAK_FP32_TFLOPS, "traffic": traffic_of(bwd_pmc),
+                         "traffic_unit": "bytes/launch (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes; quoted only if the "
+                                         "committed summary was taken from these kernel sources; algorithmic: %d)" % (R * 96 + K * W * H * 32),
+                         "executed_valu_util": bwd_pmc.get("valu_util") if bwd_pmc.get("csrc_sha1") == csrc_hash() else None,
+                         "note": "fp32 VALU / transcendental-bound reverse compositor (not MFMA, not HBM): NOTIONAL fraction = 87 fp32 flop x "
+                                 "interactions per launch / HIP-event launch time / fp32 vector peak; culling skips most lane-operations, so "
+                                 "executed_valu_util (VALU busy cycles / total, from PMC) is the pipe utilisation",
+                         "avg_launch_ms": t_bwd * 1e3, "launch_covers_views": K},
             "roofline_other": {
-                "k_render_fwd": {"bound": "mfma", "achieved": FLOP_FWD * inter / t_fwd / 1e12 if t_fwd > 0 else 0.0,
-                                 "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "avg_launch_ms": t_fwd * 1e3},
-                "k_preprocess": {"bound": "hbm", "achieved": pre_bytes / t_pre / 1e9 if t_pre > 0 else 0.0, "peak": PEAK_HBM_GBS,
-                                 "unit": "GB/s", "avg_launch_ms": t_pre * 1e3, "algorithmic_bytes": pre_bytes},
-                "k_gaussian_bwd": {"bound": "hbm", "achieved": gb_bytes / t_gb / 1e9 if t_gb > 0 else 0.0,
-                                   "peak": PEAK_HBM_GBS, "unit": "GB/s", "avg_launch_ms": t_gb * 1e3,
-                                   "algorithmic_bytes": gb_bytes}},
-            "single_stream": {"ms_per_step": 1e3 * elapsed_single / a.steps, "value_rank0": inter * a.steps / elapsed_single,
-                              "note": "same K steps, one frame at a time on one HIP stream (sequential tracking iterations)"},
-            "host_enqueue_ms_per_step": 1e3 * t_enqueued / a.steps,
+                "k_render_fwd": {"bound": "valu", "achieved": FLOP_FWD * inter / t_fwd / 1e12 if t_fwd > 0 else 0.0, "peak": PEAK_FP32_TFLOPS,
+                                 "unit": "TFLOP/s", "frac": FLOP_FWD * inter / t_fwd / 1e12 / PEAK_FP32_TFLOPS if t_fwd > 0 else 0.0,
+                                 "avg_launch_ms": t_fwd * 1e3},
+                "k_preprocess": hbm("k_preprocess", "preprocess", pre_bytes),
+                "k_scatter_instances": hbm("k_scatter_instances", "scatter_instances", scat_bytes),
+                "k_tile_sort_records": hbm("k_tile_sort_records", "tile_sort_records", sort_bytes),
+                "k_gaussian_bwd_batch": hbm("k_gaussian_bwd_batch", "gaussian_bwd", gb_bytes)},
             "stage_ms_per_step": {k: v / a.steps for k, v in prof.ms.items() if prof.launches[k]},
+            "single_stream": {"ms_per_frame": 1e3 * elapsed_single / n_single, "value_rank0": inter_1 * n_single / elapsed_single,
+                              "stage_ms_per_frame": {k: v / n_single for k, v in prof1.ms.items() if prof1.launches[k]},
+                              "k_render_bwd_frac": FLOP_BWD * inter_1 / t1_bwd / 1e12 / PEAK_FP32_TFLOPS if t1_bwd > 0 else 0.0,
+                              "k_render_fwd_frac": FLOP_FWD * inter_1 / t1_fwd / 1e12 / PEAK_FP32_TFLOPS if t1_fwd > 0 else 0.0,
+                              "note": "the window's keyframes one at a time through the single-view entry points on one HIP stream (sequential "
+                                      "tracking iterations), no host sync per frame"},
+            "host_enqueue_ms_per_step": 1e3 * t_enqueued / a.steps,
+            "csrc_sha1": csrc_hash(),
         }
-        for k in ("k_render_fwd", "k_preprocess", "k_gaussian_bwd"):
-            o = out["roofline_other"][k]
-            o["frac"] = o["achieved"] / o["peak"]
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cam, sc, deg, a.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(cams[0], sc, deg, a.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
-def shf_in(M):
-    """bytes of SH coefficients per Gaussian (fp32, 3 channels)."""
-    return 3 * M * 4
-
-
-def pmc_traffic(kernel):
-    """Memory-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes over this same
-    command (FETCH_SIZE and WRITE_SIZE, in KB, each collected in its own --pmc run; FETCH_SIZE doubled
-    for 16-B/lane streaming reads as MI355X_MICROARCH.md prescribes for gfx950).  None if the summary
-    is not in the tree: PMC counters cannot be read from inside the timed process."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_fetch_write_kb.json")
+def pmc_summary():
+    """The committed rocprofv3 PMC summary (profiles/r02_pmc_summary.json: FETCH_SIZE / WRITE_SIZE in KB per launch, each from
+    its own --pmc pass, and VALU busy / total cycles), or None.  PMC counters cannot be read from inside the timed process."""
     try:
-        with open(path) as f:
-            k = json.load(f)[kernel]
-        return (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
-    except (OSError, KeyError, ValueError):
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
         return None
 
 
+def traffic_of(k):
+    """Memory-side bytes per launch (2 x FETCH_SIZE + WRITE_SIZE: FETCH_SIZE doubled for 16-B/lane streaming reads as
+    MI355X_MICROARCH.md prescribes for gfx950) -- only if the summary was collected from the kernel sources being run."""
+    if not k or k.get("csrc_sha1") != csrc_hash() or "FETCH_SIZE" not in k:
+        return None
+    return (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
+
+
 def cpu_baseline(cam, sc, deg, budget_s):
-    """The CPU oracle (a C port of the reference's rasteriser semantics, single thread) on whole
-    frames of the same workload, repeated until the budget is spent."""
+    """The CPU oracle (a C port of the reference's rasteriser semantics) on whole frames of the same workload, forward +
+    backward: on ONE host core and on ALL host cores (tiles are independent: OpenMP over tiles / Gaussians, results identical),
+    and the dense NumPy-semantics oracle (every Gaussian at every pixel) at N = 15 / 640x480 and N = 256 / 160x120."""
+    from oracle import dense_oracle as dor
     from oracle import oracle as orc
 
     W, H = cam["W"], cam["H"]
     rng = np.random.default_rng(1234)
     dLc = (rng.normal(size=(3, H, W)) / (3 * H * W)).astype(np.float32)
     dLd = (rng.normal(size=(1, H, W)) / (H * W)).astype(np.float32)
-    reps, inter, t0 = 0, 0, time.perf_counter()
-    while True:
-        out, st = orc.forward(sc["means3D"], sc["opacities"], cam["viewmatrix"], cam["projmatrix"], cam["campos"],
-                              cam["tanfovx"], cam["tanfovy"], W, H, np.zeros(3, np.float32), shs=sc["shs"],
-                              scales=sc["scales"], rotations=sc["rotations"], sh_degree=deg)
-        orc.backward(st, dLc, dLd, cam["projmatrix_raw"])
-        reps += 1
-        inter += st["interactions"]
+    ncpu = os.cpu_count() or 1
+
+    def tiled(threads, budget):
+        used = orc.set_threads(threads)
+        reps, inter, t0 = 0, 0, time.perf_counter()
+        while True:
+            out, st = orc.forward(sc["means3D"], sc["opacities"], cam["viewmatrix"], cam["projmatrix"], cam["campos"], cam["tanfovx"],
+                                  cam["tanfovy"], W, H, np.zeros(3, np.float32), shs=sc["shs"], scales=sc["scales"],
+                                  rotations=sc["rotations"], sh_degree=deg)
+            orc.backward(st, dLc, dLd, cam["projmatrix_raw"])
+            reps += 1
+            inter += st["interactions"]
+            el = time.perf_counter() - t0
+            if el >= budget or reps >= 16:
+                break
+        orc.set_threads(1)
+        return {"value": inter / el, "unit": "interactions/s", "cores": used, "kind": "port",
+                "sample": "%d full frame(s) of the same workload (forward + backward), %.1f s on %d of %d host cores" % (reps, el, used, ncpu)}
+
+    def dense(N, w, h):
+        c = dict(cam)
+        m2 = np.stack([rng.uniform(0, w, N), rng.uniform(0, h, N)], 1)
+        A = rng.normal(size=(N, 2, 2))
+        c2 = A @ A.transpose(0, 2, 1) * (0.02 * w) ** 2 + 4.0 * np.eye(2)
+        col, dep, op = rng.uniform(0, 1, (N, 3)), np.sort(rng.uniform(1, 4, N)), rng.uniform(0.3, 0.9, N)
+        gc = rng.choice([-1.0, 0.0, 1.0], size=(h, w, 3)).astype(np.float32)
+        gd = rng.choice([-1.0, 0.0, 1.0], size=(h, w)).astype(np.float32)
+        t0 = time.perf_counter()
+        dor.dense_backward(m2, c2, col, dep, op, gc, gd)
         el = time.perf_counter() - t0
-        if el >= budget_s or reps >= 8:
-            break
-    return {"value": inter / el, "unit": "interactions/s", "cores": 1, "kind": "port",
-            "sample": "%d full frame(s) of the same workload (forward + backward), %.1f s on 1 of %d host cores"
-                      % (reps, el, os.cpu_count())}
+        del c
+        return {"value": N * w * h / el, "unit": "Gaussian-pixel pairs/s (dense semantics, backward)", "cores": ncpu,
+                "sample": "N=%d at %dx%d, one pass, %.1f s (NumPy, multi-threaded BLAS-free elementwise: effectively 1 core)" % (N, w, h, el)}
+
+    res = tiled(0, 0.35 * budget_s)            # primary: all host cores
+    res["single_core"] = tiled(1, 0.35 * budget_s)
+    res["dense_mode"] = {"N15_640x480": dense(15, 640, 480), "N256_160x120": dense(256, 160, 120)}
+    return res
 
 
 if __name__ == "__main__":

@@ -379,7 +379,11 @@ class BatchContext:
     per-Gaussian parameter gradients summed over the K views in-kernel, in the flat bucket of gsaj.keyframe_shard (one
     all-reduce ships it, tail = the K pose-gradient rows)."""
 
-    def __init__(self, K, P, W, H, M, device, has_scales=True, record_bits=32, per_gaussian_tau=False, grad_slots=1):
+    def __init__(self, K, P, W, H, M, device, has_scales=True, record_bits=32, per_gaussian_tau=False, grad_slots=1,
+                 n_windows=1, window=0):
+        """n_windows > 1 (multi-GPU: one window per rank): the bucket's tail has a dL/dtau row for every keyframe of every
+        window; this context writes the rows of window `window` and keeps the others zero, so that the ONE sum all-reduce of
+        the bucket also gathers the pose gradients of all ranks."""
         from .keyframe_shard import bucket_numel, bucket_views
         lib = _lib.load()
         self.lib, self.K, self.P, self.W, self.H, self.M, self.dev = lib, int(K), int(P), int(W), int(H), int(M), torch.device(device)
@@ -399,13 +403,13 @@ class BatchContext:
         self.capacity, self.tile_list_capacity, self.bin_stride = 0, 0, 0
         self.buckets, self.slots = [], []
         for _ in range(max(1, grad_slots)):
-            bucket = torch.zeros(bucket_numel(P, M, has_scales, K), **f)
-            v = bucket_views(bucket, P, M, has_scales, K)
+            bucket = torch.zeros(bucket_numel(P, M, has_scales, K * n_windows), **f)
+            v = bucket_views(bucket, P, M, has_scales, K * n_windows)
             self.buckets.append(bucket)
             self.slots.append(dict(mean2D=torch.zeros((K, P, 3), **f), opacity=v["opacity"], mean3D=v["mean3D"],
                                    cov3D=v["cov3D"] if not has_scales else torch.zeros((P, 6), **f), sh=v["sh"].view(P, M, 3),
                                    scale=v.get("scale"), rot=v.get("rot"), tau=torch.zeros((K, P, 6), **f) if per_gaussian_tau else None,
-                                   tau_all=v["tau_all"]))
+                                   tau_all=v["tau_all"][window * K:(window + 1) * K], tau_every_window=v["tau_all"] if n_windows > 1 else None))
         self.bucket, self.g = self.buckets[0], self.slots[0]
 
     def _size(self, capacity):
@@ -461,6 +465,8 @@ class BatchContext:
     def backward(self, bg, means3D, viewmatrices, projmatrices, projmatrix_raw, campos, tanfovx, tanfovy, dL_dcolor, dL_ddepth,
                  sh_degree=0, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, scale_modifier=1.0, slot=0):
         g = self.slots[slot]
+        if g["tau_every_window"] is not None:
+            g["tau_every_window"].zero_()  # rows of the other ranks' windows must be zero before the sum all-reduce
         _lib.check(self.lib.gsaj_rasterize_backward_batch(
             self.K, self.P, int(sh_degree), self.M, self.capacity, _ptr(bg), self.W, self.H, _ptr(means3D), _ptr(shs),
             _ptr(colors_precomp), _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrices),

@@ -244,6 +244,16 @@ work = ks.allreduce_gaussian_grads(b2, async_op=True)
 work.wait()
 for k in range(K):
     assert torch.equal(v2["tau_all"][k], torch.arange(6) + 100.0 * k)
+# batched windows (gsaj.rasterizer.BatchContext(n_windows=world, window=rank)): K rows per rank in the tail, the others zero
+KW = 3
+b3 = torch.zeros(ks.bucket_numel(P, M, True, KW * 2))
+v3 = ks.bucket_views(b3, P, M, True, KW * 2)
+v3["mean3D"][:] = float(rank + 1)
+v3["tau_all"][rank * KW:(rank + 1) * KW] = torch.arange(KW * 6, dtype=torch.float32).view(KW, 6) + 1000.0 * rank
+ks.allreduce_gaussian_grads(b3)
+assert torch.equal(v3["mean3D"], torch.full_like(v3["mean3D"], 3.0))
+for r in range(2):
+    assert torch.equal(v3["tau_all"][r * KW:(r + 1) * KW], torch.arange(KW * 6, dtype=torch.float32).view(KW, 6) + 1000.0 * r)
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
