@@ -1,8 +1,11 @@
 """Parameter store + activations of the Gaussian map: the part of the reference's
 GaussianModel that the render path reads (gaussian_splatting/scene/gaussian_model.py:141-177:
 get_xyz, get_features, get_opacity, get_scaling, get_rotation, get_covariance,
-active_sh_degree / max_sh_degree).  Densification, pruning, optimiser surgery, PLY and
-TorchScript I/O (:70-138, :281-771) are callers' business and out of scope here.
+active_sh_degree / max_sh_degree), plus what sits directly either side of it: the
+densification bookkeeping fed by a backward (add_densification_stats :767-771, max_radii2D, n_obs --
+one device launch, gsaj_densification_stats) and parameter I/O in the reference's formats
+(load_tensors :70-138, save_ply :402-436, load_ply :453-542; gsaj.model_io).  The densify / prune /
+optimiser-surgery logic itself (:281-765) stays the caller's.
 """
 import torch
 
@@ -72,3 +75,86 @@ class GaussianModel:
 
     def parameters(self):
         return [self._xyz, self._features_dc, self._features_rest, self._opacity, self._scaling, self._rotation]
+
+    # ---- bookkeeping tensors + parameter I/O -----------------------------------------------------------
+    def _init_aux(self):
+        """The auxiliary tensors load_tensors / load_ply create (gaussian_model.py:124-131, 538-542)."""
+        n, dev = self._xyz.shape[0], self._xyz.device
+        self.max_radii2D = torch.zeros((n,), device=dev)
+        self.xyz_gradient_accum = torch.zeros((n, 1), device=dev)
+        self.denom = torch.zeros((n, 1), device=dev)
+        self.unique_kfIDs = torch.zeros((n,)).int()
+        self.n_obs = torch.zeros((n,)).int()
+
+    def _set_params(self, xyz, f_dc, f_rest, opacity, scaling, rotation, device):
+        t = lambda a: torch.as_tensor(a, dtype=torch.float32).to(device).contiguous().requires_grad_(True)  # noqa: E731
+        self._xyz, self._features_dc, self._features_rest = t(xyz), t(f_dc), t(f_rest)
+        self._opacity, self._scaling, self._rotation = t(opacity), t(scaling), t(rotation)
+        self._init_aux()
+
+    def load_tensors(self, model_path, device="cuda"):
+        """Reference load_tensors (:70-138): parameters in stored order xyz, f_dc, f_rest, opacity, scaling, rotation; a 2-D f_dc
+        becomes [P,1,3]; active_sh_degree is left as it is (the reference never raises it here).  Nothing in the file is
+        executed (gsaj.model_io.read_parameter_tensors).  Returns True / False like the reference."""
+        from gsaj.model_io import read_parameter_tensors
+        try:
+            ts = read_parameter_tensors(model_path)
+            if len(ts) < 6:
+                raise ValueError("expected 6 parameter tensors, found %d" % len(ts))
+            xyz, f_dc, f_rest, opacity, scaling, rotation = ts[:6]
+            if f_dc.dim() == 2:
+                f_dc = f_dc.unsqueeze(1)
+            self._set_params(xyz, f_dc, f_rest, opacity, scaling, rotation, device)
+            return True
+        except Exception as e:  # noqa: BLE001 -- the reference reports and returns False
+            print("Error loading tensors from %s: %s" % (model_path, e))
+            return False
+
+    def construct_list_of_attributes(self):
+        from gsaj.model_io import ply_attributes
+        return ply_attributes(self._features_dc.shape[1] * self._features_dc.shape[2], self._features_rest.shape[1] * self._features_rest.shape[2],
+                              self._scaling.shape[1], self._rotation.shape[1])
+
+    def save_ply(self, path):
+        import os
+        from gsaj.model_io import write_ply
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        d = lambda x: x.detach().cpu().numpy()  # noqa: E731
+        write_ply(path, d(self._xyz), d(self._features_dc), d(self._features_rest), d(self._opacity), d(self._scaling), d(self._rotation))
+
+    def load_ply(self, path, device="cuda"):
+        from gsaj.model_io import read_gaussian_ply
+        g = read_gaussian_ply(path, self.max_sh_degree)
+        self._set_params(g["xyz"], g["f_dc"], g["f_rest"], g["opacity"], g["scaling"], g["rotation"], device)
+        self.ply_input = dict(points=g["xyz"], normals=g["normals"])
+        self.active_sh_degree = self.max_sh_degree
+
+    def add_densification_stats(self, viewspace_point_tensor, update_filter):
+        """Reference :767-771, one device launch: xyz_gradient_accum[f] += ||grad[f, :2]||, denom[f] += 1.  update_filter is the
+        view's visibility filter (radii > 0), as every caller passes it (slam_backend.py:119, 282)."""
+        self.densification_step(viewspace_point_tensor.grad[None], update_filter[None].to(torch.int32), None, update_max_radii=False)
+
+    def densification_step(self, dL_dmean2D, radii, n_touched=None, update_max_radii=True):
+        """All bookkeeping of one mapping iteration over K views in ONE launch: dL_dmean2D [K,P,3] (BatchContext's g["mean2D"] or
+        stacked viewspace_points.grad), radii [K,P] int32, n_touched [K,P] int32 or None.  Updates xyz_gradient_accum, denom,
+        max_radii2D (visible = radii > 0) and, with n_touched, n_obs = number of views that touched each Gaussian
+        (slam_backend.py:113-121, 236-250, 276-285)."""
+        from gsaj import _lib
+        lib = _lib.load()
+        K, P = radii.shape
+        g = dL_dmean2D.to(torch.float32).contiguous()
+        r = radii.to(torch.int32).contiguous()
+        nt = None if n_touched is None else n_touched.to(torch.int32).contiguous()
+        dev = g.device
+        n_obs = torch.zeros((P,), dtype=torch.int32, device=dev) if nt is not None else None
+        if self.max_radii2D.device != dev:
+            self.max_radii2D = self.max_radii2D.to(dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.gsaj_densification_stats(K, P, g.data_ptr(), r.data_ptr(), None if nt is None else nt.data_ptr(),
+                                                    self.xyz_gradient_accum.data_ptr(), self.denom.data_ptr(),
+                                                    self.max_radii2D.data_ptr() if update_max_radii else None,
+                                                    None if n_obs is None else n_obs.data_ptr(),
+                                                    torch.cuda.current_stream(dev).cuda_stream), "gsaj_densification_stats")
+        if n_obs is not None:
+            self.n_obs = n_obs
+        return n_obs

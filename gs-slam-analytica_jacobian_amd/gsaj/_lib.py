@@ -57,6 +57,7 @@ SIGNATURES = {
     "gsaj_pose_state_floats": (c_int, []),
     "gsaj_pose_adam_step": (c_int, [P, P] + [c_float] * 8 + [P, P, P]),
     "gsaj_loss_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "gsaj_densification_stats": (c_int, [c_int, c_int] + [P] * 7 + [P]),
     "gsaj_isotropic_workspace_bytes": (c_size_t, [c_int]),
     "gsaj_isotropic_loss": (c_int, [c_int, c_int, c_float, P, P, c_int, P, P, P]),
     "gsaj_loss_seeds": (c_int, [c_int, c_int, c_int, c_float, c_float] + [P] * 8 + [P] * 4 + [P, P]),

@@ -252,6 +252,17 @@ size_t gsaj_isotropic_workspace_bytes(int P);
 int gsaj_isotropic_loss(int P, int C, float weight, const float *scales, float *dL_dscales, int accumulate, float *out_loss,
                         void *iso_ws, void *stream);
 
+/* ---- densification / pruning bookkeeping ----------------------------------------------------------
+ * What the reference's mapping loop does per rendered view after the backward (utils/slam_backend.py:113-121, 276-285):
+ *   vis = radii > 0;  max_radii2D[vis] = max(max_radii2D[vis], radii[vis]);
+ *   xyz_gradient_accum[vis] += ||viewspace_points.grad[vis, :2]||;  denom[vis] += 1        (gaussian_model.py:767-771)
+ * and, for pruning, n_obs = number of views that touched the Gaussian (n_touched > 0; slam_backend.py:236-250), for the K
+ * views of a window in ONE launch (K = 1: one view).  dL_dmean2D [K,P,3] (the backward's per-view output), radii [K,P],
+ * n_touched [K,P] (may be NULL); xyz_gradient_accum [P], denom [P], max_radii2D [P] are updated in place (each may be NULL),
+ * n_obs [P] int32 is written (may be NULL). */
+int gsaj_densification_stats(int K, int P, const float *dL_dmean2D, const int *radii, const int *n_touched,
+                             float *xyz_gradient_accum, float *denom, float *max_radii2D, int *n_obs, void *stream);
+
 /* ---- tracking pose step on the device -------------------------------------------
  * One launch = torch.optim.Adam.step() on (cam_trans_delta, cam_rot_delta, exposure_a, exposure_b) as set up in
  * slam_frontend.py:135-160 + update_pose (reference utils/pose_utils.py:76-93) + the camera matrices of
