@@ -511,13 +511,107 @@ int launch_gaussian_backward(const BwdParams &p, const GeomWS &g, const BinWS &b
 // ---- batched: K views of one map, per-Gaussian parameter gradients summed over the views IN-KERNEL --------------------
 // A mapping window renders every keyframe against the same Gaussians and back-propagates once, so the per-Gaussian
 // gradients accumulate over keyframes while every keyframe keeps its own dL/dtau (reference utils/slam_backend.py:168-232).
-// One workgroup = 64 Gaussians x NW waves (NW = min(K, 8)), wave w taking views w, w + NW, ...: the Gaussian's SH block is
-// read ONCE for all K views (staged in LDS, shared by the waves), every wave streams its view's instance rows exactly like
-// the single-view kernel and runs the same per-Gaussian chain (gaussian_chain: same bits per view), and the views' results
-// are added into ONE LDS row per Gaussian in VIEW ORDER (the waves take turns) -- fixed order end to end, bit-reproducible.
-// The summed gradients are written once instead of K times; dL/dSH is summed in its factored form w_k(view dir) * g[ch].
+// Two launches:
+//  k_gather_sums (grid x K, HBM-streaming, many waves in flight): a Gaussian's per-instance partial-gradient rows -- one
+//    contiguous run by emission slot, a wave's 64 Gaussians one contiguous block -- are streamed through LDS with coalesced
+//    loads and added in emission order (the single-view kernel's gather, on its own so that its two dependent memory round
+//    trips overlap across ~6 waves per SIMD instead of stalling a register-heavy kernel); 48 bytes per Gaussian and view out.
+//  k_gaussian_bwd_batch: one workgroup = 64 Gaussians x NW waves (NW = min(K, 8)), wave w taking views w, w + NW, ...: the
+//    Gaussian's SH block is read ONCE for all K views (staged in LDS, shared by the waves), every wave runs the same
+//    per-Gaussian chain as the single-view kernel (gaussian_chain) on its view's sums, and the views' results are added
+//    into ONE LDS row per Gaussian in VIEW ORDER (the waves take turns) -- fixed order end to end, bit-reproducible.  The
+//    summed gradients are written once instead of K times; dL/dSH is summed in its factored form w_k(view dir) * g[ch].
+// k_gather_sums: lane = ROW.  A wave owns 64 consecutive Gaussians, whose instance rows are ONE contiguous block ordered by
+// owner; it walks the block 64 rows at a time with fully coalesced loads (row + `reached` flag requested together: one memory
+// round trip; the next 64 rows are requested before the current ones are reduced), finds every row's owner by a 6-step binary
+// search over the owners' end slots (lane shuffles), runs a scan-by-key over the 64 rows (Hillis-Steele, add when the owner of
+// lane l equals the owner of lane l - d: exact for contiguous segments), and each owner picks up its segment's total from its
+// segment's last row of the group.  No LDS staging, no per-lane loop over a heavy-tailed run length (that loop kept ~20 % of
+// the lanes busy and its scattered ds_read_b128 conflicted 4-way: 100 us; this form: see profiles/).  The additions follow a
+// fixed tree per 64-row group and the groups in order: bit-reproducible.
+__global__ __launch_bounds__(256) void k_gather_sums(int P, const int *__restrict__ radii0, GeomWS g0, ImageWS im0,
+                                                     const float4 *__restrict__ inst_grad0, const uint8_t *__restrict__ reached0,
+                                                     ViewStrides vs) {
+  const size_t view = blockIdx.y;
+  const GeomWS g = geom_view(g0, view * vs.geom);
+  const float4 *inst_grad = gsaj_shift(inst_grad0, view * vs.bin);
+  const uint8_t *reached = gsaj_shift(reached0, view * vs.bin);
+  const uint32_t *counters = gsaj_shift(im0.counters, view * vs.image);
+  const int lane = threadIdx.x & 63;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const size_t ii = (size_t)(idx < P ? idx : 0);
+  const bool live = idx < P && counters[4] == 0u;  // (an aborted async frame contributes nothing)
+  const uint32_t cnt = live ? g.tiles_touched[ii] : 0u;
+  const uint32_t endi_raw = live ? g.point_offsets[ii] : 0u;
+  // owners' end slots, made non-decreasing over the lanes (culled / out-of-range owners repeat their predecessor's end)
+  uint32_t endi = endi_raw;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t up = (uint32_t)__shfl_up((int)endi, o);
+    if (lane >= o) endi = max(endi, up);
+  }
+  const uint32_t first = live ? endi_raw - cnt : endi;
+  uint32_t F = (cnt > 0) ? first : 0xffffffffu;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) F = min(F, (uint32_t)__shfl_xor((int)F, o));
+  const uint32_t E = (uint32_t)__shfl((int)endi, 63);
+  float sum[10];
+#pragma unroll
+  for (int c = 0; c < 10; c++) sum[c] = 0.f;
+  if (F != 0xffffffffu && F < E) {
+    float4 a0, a1, a2;
+    uint8_t fl;
+    auto request = [&](uint32_t base) {
+      const uint32_t r = min(base + (uint32_t)lane, E - 1);
+      fl = reached[r];
+      const float4 *src = inst_grad + (size_t)r * REC_F4;
+      a0 = src[0]; a1 = src[1]; a2 = src[2];
+    };
+    request(F);
+    for (uint32_t base = F; base < E; base += 64) {
+      const uint32_t r = base + (uint32_t)lane;
+      const bool ok = r < E && fl;
+      float v[10] = {ok ? a0.x : 0.f, ok ? a0.y : 0.f, ok ? a0.z : 0.f, ok ? a0.w : 0.f, ok ? a1.x : 0.f,
+                     ok ? a1.y : 0.f, ok ? a1.z : 0.f, ok ? a1.w : 0.f, ok ? a2.x : 0.f, ok ? a2.y : 0.f};
+      if (base + 64 < E) request(base + 64);
+      // owner of row r = number of owners whose end slot is <= r (end slots are non-decreasing): binary search by shuffles
+      int own = 0;
+#pragma unroll
+      for (int step = 32; step > 0; step >>= 1) {
+        const uint32_t e = (uint32_t)__shfl((int)endi, own + step - 1);
+        if (e <= r) own += step;
+      }
+      // scan by key: after the last step lane l holds the sum of the rows of its owner in [max(segment start, base), r]
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int own_up = __shfl_up(own, d);
+        const bool same = lane >= d && own_up == own;
+#pragma unroll
+        for (int c = 0; c < 10; c++) {
+          const float up = __shfl_up(v[c], d);
+          v[c] += same ? up : 0.f;
+        }
+      }
+      // every owner whose run meets this group takes the total at its run's last row inside the group
+      const uint32_t run_lo = max(first, base), run_hi = min(first + cnt, min(base + 64u, E));
+      const bool mine = cnt > 0 && run_lo < run_hi;
+      const int q = mine ? (int)(run_hi - 1u - base) : 0;
+#pragma unroll
+      for (int c = 0; c < 10; c++) {
+        const float t = __shfl(v[c], q);
+        sum[c] += mine ? t : 0.f;
+      }
+    }
+  }
+  if (idx < P) {
+    g.gsum[3 * ii + 0] = make_float4(sum[0], sum[1], sum[2], sum[3]);
+    g.gsum[3 * ii + 1] = make_float4(sum[4], sum[5], sum[6], sum[7]);
+    g.gsum[3 * ii + 2] = make_float4(sum[8], sum[9], 0.f, 0.f);
+  }
+  (void)radii0;
+}
+
 #define GBB_MAX_WAVES 8
-#define GBB_ROWS 128  // instance rows staged per wave per trip
 template <int SHW>
 __global__ __launch_bounds__(GB_BLOCK * GBB_MAX_WAVES) void k_gaussian_bwd_batch(BwdParams p, int K, GeomWS g0, ImageWS im0,
                                                                                  const float4 *__restrict__ inst_grad0,
@@ -527,14 +621,15 @@ __global__ __launch_bounds__(GB_BLOCK * GBB_MAX_WAVES) void k_gaussian_bwd_batch
                                                                                  float *__restrict__ pv_tau) {
   constexpr int NACC = 17 + SHW;  // opacity, mean3D 3, cov3D 6, scale 3, rot 4, dL/dSH
   constexpr int MC = SHW / 3;     // SH coefficients stored
-  constexpr int shs_stride = SHW + 1, mstride = NACC + 1;
-  extern __shared__ float lds_dyn[];  // [64][SHW+1] SH coefficients | [64][NACC+1] sums | NW x GBB_ROWS x 3 float4 row staging
+  constexpr int shs_stride = SHW + 1;
+  extern __shared__ float lds_dyn[];  // [64][SHW+1] SH coefficients | [NW][NACC][64] per-wave sums (component-major: conflict-free)
   __shared__ uint32_t s_ticket;
   const int tid = threadIdx.x & 63, wave = threadIdx.x >> 6, NW = blockDim.x >> 6;
   const int idx = blockIdx.x * GB_BLOCK + tid;
   float *sh_in = lds_dyn;
-  float *meet = lds_dyn + ((GB_BLOCK * shs_stride + 3) & ~3);
-  float4 *rows = reinterpret_cast<float4 *>(meet + ((GB_BLOCK * mstride + 3) & ~3)) + wave * GBB_ROWS * REC_F4;
+  float *meet_all = lds_dyn + ((GB_BLOCK * shs_stride + 3) & ~3);
+  constexpr int CS = GB_BLOCK + 1;  // component stride (padded: the transposed dL/dSH store below stays conflict-free)
+  float *mine = meet_all + (size_t)wave * NACC * CS + tid;  // this wave's private sums: component k at mine[k * CS]
   const size_t ii = (size_t)(idx < p.P ? idx : 0);
   // ---- inputs of this Gaussian: once for all views ----
   const float3 mean = make_float3(p.means3D[3 * ii], p.means3D[3 * ii + 1], p.means3D[3 * ii + 2]);
@@ -555,7 +650,7 @@ __global__ __launch_bounds__(GB_BLOCK * GBB_MAX_WAVES) void k_gaussian_bwd_batch
       sh_in[gi * shs_stride + k] = p.shs[base + e];
     }
   }
-  for (int e = threadIdx.x; e < GB_BLOCK * mstride; e += (int)blockDim.x) meet[e] = 0.f;
+  for (int e = threadIdx.x; e < NW * NACC * CS; e += (int)blockDim.x) meet_all[e] = 0.f;
   __syncthreads();
   const float *vm0 = p.viewmatrix, *pj0 = p.projmatrix, *cam0 = p.campos;
   const int *radii0 = p.radii;
@@ -573,8 +668,6 @@ __global__ __launch_bounds__(GB_BLOCK * GBB_MAX_WAVES) void k_gaussian_bwd_batch
     float gmask[3] = {0.f, 0.f, 0.f};
     if (v < K) {
       const GeomWS g = geom_view(g0, (size_t)v * vs.geom);
-      const float4 *inst_grad = gsaj_shift(inst_grad0, (size_t)v * vs.bin);
-      const uint8_t *reached = gsaj_shift(reached0, (size_t)v * vs.bin);
       const uint32_t *counters = gsaj_shift(im0.counters, (size_t)v * vs.image);
       p.viewmatrix = vm0 + 16 * v;
       p.projmatrix = pj0 + 16 * v;
@@ -582,48 +675,10 @@ __global__ __launch_bounds__(GB_BLOCK * GBB_MAX_WAVES) void k_gaussian_bwd_batch
       const bool aborted = counters[4] != 0u;  // aborted async frame: contributes nothing
       const int radius = (idx < p.P && !aborted) ? radii0[(size_t)v * p.P + ii] : 0;
       const bool vis = radius > 0;
-      const uint32_t cnt = (idx < p.P && !aborted) ? g.tiles_touched[ii] : 0u;
-      const uint32_t endi = (idx < p.P && !aborted) ? g.point_offsets[ii] : 0u;
-      const uint32_t first = endi - cnt;
-      const uint32_t F = (uint32_t)__shfl((int)first, 0);
-      uint32_t E = endi;
-#pragma unroll
-      for (int o2 = 32; o2 > 0; o2 >>= 1) E = max(E, (uint32_t)__shfl_xor((int)E, o2));
       uint8_t cl[3] = {0, 0, 0};
       if (SHW > 0) { cl[0] = g.clamped[3 * ii]; cl[1] = g.clamped[3 * ii + 1]; cl[2] = g.clamped[3 * ii + 2]; }
-      // gather this wave's contiguous block of instance rows through LDS, each lane summing its own rows in emission order
-      float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0;
-      for (uint32_t lo = F; lo < E; lo += GBB_ROWS) {
-        const uint32_t hi = min(lo + (uint32_t)GBB_ROWS, E);
-        float4 a[GBB_ROWS / 64][3];
-#pragma unroll
-        for (int w = 0; w < GBB_ROWS / 64; w++) {
-          const uint32_t r = lo + (uint32_t)(w * 64 + tid);
-          a[w][0] = a[w][1] = a[w][2] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (r < hi && reached[r]) {
-            const float4 *src = inst_grad + (size_t)r * REC_F4;
-            a[w][0] = src[0]; a[w][1] = src[1]; a[w][2] = src[2];
-          }
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int w = 0; w < GBB_ROWS / 64; w++) {
-          rows[(w * 64 + tid) * REC_F4 + 0] = a[w][0];
-          rows[(w * 64 + tid) * REC_F4 + 1] = a[w][1];
-          rows[(w * 64 + tid) * REC_F4 + 2] = a[w][2];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const uint32_t ub = max(first, lo), ue = min(first + cnt, hi);
-        for (uint32_t u = ub; u < ue; u++) {
-          const float4 a0 = rows[(u - lo) * REC_F4 + 0], a1 = rows[(u - lo) * REC_F4 + 1], a2 = rows[(u - lo) * REC_F4 + 2];
-          s0.x += a0.x; s0.y += a0.y; s0.z += a0.z; s0.w += a0.w;
-          s1.x += a1.x; s1.y += a1.y; s1.z += a1.z; s1.w += a1.w;
-          s2.x += a2.x; s2.y += a2.y;
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
+      // the Gaussian's 10 reverse-compositor sums of this view (k_gather_sums)
+      const float4 s0 = g.gsum[3 * ii + 0], s1 = g.gsum[3 * ii + 1], s2 = g.gsum[3 * ii + 2];
       float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       if (vis) {
         gaussian_chain<true>(p, mean, c6, sc, q, cl, s0, s1, s2, sh_in + tid * shs_stride, shw, p.scales != nullptr, o, tau);
@@ -649,26 +704,32 @@ __global__ __launch_bounds__(GB_BLOCK * GBB_MAX_WAVES) void k_gaussian_bwd_batch
         if (tid == 0) __hip_atomic_store(&g.tau_partials[(size_t)blockIdx.x * 8 + k], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    // ---- the views of this round are added to the Gaussian's LDS row in view order: the waves take turns ----
-    for (int w = 0; w < NW; w++) {
-      if (wave == w && v < K) {
-        float *m = meet + tid * mstride;
-        m[0] += o.op;
-        m[1] += o.gm.x; m[2] += o.gm.y; m[3] += o.gm.z;
+    // ---- this view is added to the wave's private sums (no other wave touches them) ----
+    if (v < K) {
+#define MADD(k, x) mine[(k) * CS] += (x)
+      MADD(0, o.op);
+      MADD(1, o.gm.x); MADD(2, o.gm.y); MADD(3, o.gm.z);
 #pragma unroll
-        for (int k = 0; k < 6; k++) m[4 + k] += o.cov[k];
-        m[10] += o.scale.x; m[11] += o.scale.y; m[12] += o.scale.z;
-        m[13] += o.rot.x; m[14] += o.rot.y; m[15] += o.rot.z; m[16] += o.rot.w;
+      for (int k = 0; k < 6; k++) MADD(4 + k, o.cov[k]);
+      MADD(10, o.scale.x); MADD(11, o.scale.y); MADD(12, o.scale.z);
+      MADD(13, o.rot.x); MADD(14, o.rot.y); MADD(15, o.rot.z); MADD(16, o.rot.w);
 #pragma unroll
-        for (int k = 0; k < MC; k++) {
-          m[17 + 3 * k] += shw[k] * gmask[0];
-          m[17 + 3 * k + 1] += shw[k] * gmask[1];
-          m[17 + 3 * k + 2] += shw[k] * gmask[2];
-        }
+      for (int k = 0; k < MC; k++) {
+        MADD(17 + 3 * k, shw[k] * gmask[0]);
+        MADD(17 + 3 * k + 1, shw[k] * gmask[1]);
+        MADD(17 + 3 * k + 2, shw[k] * gmask[2]);
       }
-      __syncthreads();
+#undef MADD
     }
   }
+  // ---- the waves' sums are added in wave order, every (component, Gaussian) by one thread: fixed order, bit-reproducible ----
+  __syncthreads();
+  for (int e = threadIdx.x; e < NACC * CS; e += (int)blockDim.x) {
+    float t = meet_all[e];
+    for (int w = 1; w < NW; w++) t += meet_all[(size_t)w * NACC * CS + e];
+    meet_all[e] = t;
+  }
+  __syncthreads();
   // ---- dL/dtau: the last workgroup to arrive sums every view's partials in workgroup order (fp64) ----
   if (threadIdx.x == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -695,23 +756,24 @@ __global__ __launch_bounds__(GB_BLOCK * GBB_MAX_WAVES) void k_gaussian_bwd_batch
   }
   // ---- outputs, once per Gaussian ----
   if (wave == 0 && idx < p.P) {
-    const float *m = meet + tid * mstride;
+#define MGET(k) meet_all[(k) * CS + tid]
     const size_t i = (size_t)idx;
-    p.dL_dopacity[i] = m[0];
-    p.dL_dmean3D[3 * i] = m[1]; p.dL_dmean3D[3 * i + 1] = m[2]; p.dL_dmean3D[3 * i + 2] = m[3];
+    p.dL_dopacity[i] = MGET(0);
+    p.dL_dmean3D[3 * i] = MGET(1); p.dL_dmean3D[3 * i + 1] = MGET(2); p.dL_dmean3D[3 * i + 2] = MGET(3);
 #pragma unroll
-    for (int k = 0; k < 6; k++) p.dL_dcov3D[6 * i + k] = m[4 + k];
+    for (int k = 0; k < 6; k++) p.dL_dcov3D[6 * i + k] = MGET(4 + k);
     if (p.scales) {
-      p.dL_dscale[3 * i] = m[10]; p.dL_dscale[3 * i + 1] = m[11]; p.dL_dscale[3 * i + 2] = m[12];
-      reinterpret_cast<float4 *>(p.dL_drot)[i] = make_float4(m[13], m[14], m[15], m[16]);
+      p.dL_dscale[3 * i] = MGET(10); p.dL_dscale[3 * i + 1] = MGET(11); p.dL_dscale[3 * i + 2] = MGET(12);
+      reinterpret_cast<float4 *>(p.dL_drot)[i] = make_float4(MGET(13), MGET(14), MGET(15), MGET(16));
     }
+#undef MGET
   }
   if (SHW > 0 && p.dL_dsh) {  // coalesced store of the [64][M*3] block (coefficients above the active degree stay zero)
     const size_t base = (size_t)blockIdx.x * GB_BLOCK * SHW;
     const int count = min(GB_BLOCK, p.P - blockIdx.x * GB_BLOCK) * SHW;
     for (int e = threadIdx.x; e < count; e += (int)blockDim.x) {
       const int gi = e / (SHW > 0 ? SHW : 1), k = e - gi * SHW;
-      p.dL_dsh[base + e] = meet[gi * mstride + 17 + k];
+      p.dL_dsh[base + e] = meet_all[(17 + k) * CS + gi];
     }
   }
 }
@@ -721,14 +783,19 @@ static void launch_gbb(const BwdParams &p, int K, const GeomWS &g, const BinWS &
   const int nblk = (p.P + GB_BLOCK - 1) / GB_BLOCK;
   const int nw = K < GBB_MAX_WAVES ? K : GBB_MAX_WAVES;
   const size_t sh_floats = ((size_t)GB_BLOCK * (SHW + 1) + 3) & ~(size_t)3;
-  const size_t meet = ((size_t)GB_BLOCK * (17 + SHW + 1) + 3) & ~(size_t)3, stage = (size_t)nw * GBB_ROWS * REC_F4 * 4;
-  const size_t lds = sizeof(float) * (sh_floats + meet + stage);
+  const size_t meet = (size_t)nw * (17 + SHW) * (GB_BLOCK + 1);
+  const size_t lds = sizeof(float) * (sh_floats + meet);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gaussian_bwd_batch<SHW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k_gaussian_bwd_batch<SHW>, dim3(nblk), dim3(GB_BLOCK * nw), lds, s, p, K, g, im, b.inst_grad, b.reached, vs,
                      p.dL_dmean2D, p.dL_dconic, p.dL_dcolor, p.dL_ddepth, p.dL_dtau);
 }
 
 int launch_gaussian_backward_batch(const BwdParams &p, int K, const GeomWS &g, const BinWS &b, const ImageWS &im, ViewStrides vs,
                                    hipStream_t s) {
+  {
+    GsajProfScope ps(ST_GATHER_SUMS, s);
+    hipLaunchKernelGGL(k_gather_sums, dim3((p.P + 255) / 256, K), dim3(256), 0, s, p.P, p.radii, g, im, b.inst_grad, b.reached, vs);
+  }
   GsajProfScope ps(ST_GAUSSIAN_BWD, s);
   switch (p.shs ? p.M : 0) {
     case 0: launch_gbb<0>(p, K, g, b, im, vs, s); break;

@@ -41,6 +41,8 @@ struct GeomWS {  // per-Gaussian state (reference: GeometryState, rasterizer_imp
   float *tau_partials;      // [nblk*8] per-workgroup dL/dtau partial sums
   float4 *splat;            // [P*3] packed per-Gaussian row the tile sort gathers with three 16-B loads:
                             //   (mean2D.x, mean2D.y, rect x0|y0<<10|w<<20, first emission slot) (conic, opacity) (rgb, -)
+  float4 *gsum;             // [P*3] batched backward: the Gaussian's 10 reverse-compositor sums (its instance rows added in
+                            //   emission order by k_gather_sums), read by k_gaussian_bwd_batch
 };
 
 static inline __host__ __device__ size_t geom_carve(char *base, size_t P, GeomWS *g) {
@@ -64,6 +66,7 @@ static inline __host__ __device__ size_t geom_carve(char *base, size_t P, GeomWS
   CARVE(block_sums, uint32_t, nblk);
   CARVE(tau_partials, float, ((P + GB_BLOCK - 1) / GB_BLOCK + 1) * 8);
   CARVE(splat, float4, P * 3);
+  CARVE(gsum, float4, P * 3);
   return off;
 }
 
@@ -138,7 +141,7 @@ __device__ __forceinline__ GeomWS geom_view(GeomWS g, size_t off) {
   g.conic_opacity = gsaj_shift(g.conic_opacity, off); g.rgb = gsaj_shift(g.rgb, off); g.clamped = gsaj_shift(g.clamped, off);
   g.tiles_touched = gsaj_shift(g.tiles_touched, off); g.point_offsets = gsaj_shift(g.point_offsets, off);
   g.internal_radii = gsaj_shift(g.internal_radii, off); g.block_sums = gsaj_shift(g.block_sums, off);
-  g.tau_partials = gsaj_shift(g.tau_partials, off); g.splat = gsaj_shift(g.splat, off);
+  g.tau_partials = gsaj_shift(g.tau_partials, off); g.splat = gsaj_shift(g.splat, off); g.gsum = gsaj_shift(g.gsum, off);
   return g;
 }
 __device__ __forceinline__ ImageWS image_view(ImageWS m, size_t off) {
@@ -182,7 +185,7 @@ void gsaj_set_error(const char *fmt, ...);
 // ---- optional per-stage timing with HIP events on the launch stream (api.hip) --------------
 enum GsajStage {
   ST_PREPROCESS = 0, ST_SCAN, ST_EMIT_KEYS, ST_SORT, ST_RANGES_RECORDS, ST_RENDER_FWD, ST_RENDER_BWD, ST_GAUSSIAN_BWD,
-  ST_TAU_FINALIZE, ST_DENSE_BWD, ST_DENSE_REDUCE, ST_SCATTER, ST_TILE_SORT, ST_COUNT
+  ST_TAU_FINALIZE, ST_DENSE_BWD, ST_DENSE_REDUCE, ST_SCATTER, ST_TILE_SORT, ST_GATHER_SUMS, ST_COUNT
 };
 void gsaj_prof_mark(int stage, int is_stop, hipStream_t s);
 struct GsajProfScope {

@@ -209,7 +209,7 @@ def debug_export(P, R, W, H, geomBuffer, binningBuffer, imageBuffer):
 
 
 STAGE_NAMES = ("preprocess,scan_blocks,emit_keys,sort,ranges_records,render_fwd,render_bwd,gaussian_bwd,tau_finalize,"
-               "dense_bwd,dense_reduce,scatter_instances,tile_sort_records").split(",")
+               "dense_bwd,dense_reduce,scatter_instances,tile_sort_records,gather_sums").split(",")
 
 
 class profile_stages:

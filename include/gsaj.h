@@ -216,8 +216,8 @@ int gsaj_debug_export(int P, int R, int W, int H, const void *geom_ws, const voi
  * bracketed by HIP events on the stream it is launched on.  gsaj_profile_end synchronises,
  * and returns per stage the summed duration in ms and the number of launches.
  * Stage order: GSAJ_STAGE_NAMES. */
-#define GSAJ_NUM_STAGES 13
-#define GSAJ_STAGE_NAMES "preprocess,scan_blocks,emit_keys,sort,ranges_records,render_fwd,render_bwd,gaussian_bwd,tau_finalize,dense_bwd,dense_reduce,scatter_instances,tile_sort_records"
+#define GSAJ_NUM_STAGES 14
+#define GSAJ_STAGE_NAMES "preprocess,scan_blocks,emit_keys,sort,ranges_records,render_fwd,render_bwd,gaussian_bwd,tau_finalize,dense_bwd,dense_reduce,scatter_instances,tile_sort_records,gather_sums"
 int gsaj_profile_begin(int max_records);
 int gsaj_profile_end(float *stage_ms /*host [GSAJ_NUM_STAGES]*/, int *stage_launches /*host [GSAJ_NUM_STAGES]*/);
 

@@ -3,7 +3,7 @@ reference's mapping window (utils/slam_backend.py:168-232: every keyframe render
 per-Gaussian gradients accumulated over keyframes, one dL/dtau per keyframe).
 
 Per view the batched launch must give the SAME BITS as the single-view entry points for everything the compositors produce
-(same kernels, gridDim.y = view: images, radii, n_touched, dL/dmean2D) and dL/dtau to fp32 rounding; the summed per-Gaussian
+(same kernels, gridDim.y = view: images, radii, n_touched) and dL/dmean2D, dL/dtau to fp32 rounding; the summed per-Gaussian
 gradients must equal the fp64 sum of the single-view gradients to fp32 rounding; and against the oracle the
 per-keyframe dL/dtau and the sum hold the tolerances of tests/helpers.py (the single-view path is verified term by term in
 test_gpu_full_size.py)."""
@@ -59,11 +59,11 @@ def _compare(bc, g, st, singles, precomp):
         assert st[k][0] == fc.true_R and not st[k][2]
         assert torch.equal(bc.color[k], fc.color) and torch.equal(bc.depth[k], fc.depth) and torch.equal(bc.opacity[k], fc.opacity)
         assert torch.equal(bc.radii[k], fc.radii) and torch.equal(bc.n_touched[k], fc.n_touched)
-        assert torch.equal(g["mean2D"][k], gs["mean2D"]), "per-view dL/dmean2D differs from the single-view kernel"
-        # the per-Gaussian chain is a separate template instantiation in the batched kernel (the compiler may fuse multiply-adds
-        # differently): dL/dtau agrees to fp32 rounding, not bit for bit
-        for a, b in ((g["tau"][k], gs["tau"]), (g["tau_all"][k], gs["tau_sum"])):
-            assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()), "per-view dL/dtau differs"
+        # the batched path adds a Gaussian's per-tile partial sums with a scan-by-key tree (k_gather_sums) where the single-view kernel
+        # adds them one after the other, and its per-Gaussian chain is a separate template instantiation (the compiler may fuse
+        # multiply-adds differently): per-view gradients agree to fp32 rounding, not bit for bit
+        for a, b, nm in ((g["mean2D"][k], gs["mean2D"], "mean2D"), (g["tau"][k], gs["tau"], "tau"), (g["tau_all"][k], gs["tau_sum"], "tau_sum")):
+            assert float((a - b).abs().max()) <= 3e-6 * float(b.abs().max()), "per-view dL/d%s differs" % nm
     names = ["mean3D", "opacity", "cov3D"] if precomp else ["mean3D", "opacity", "sh", "scale", "rot"]
     for n in names:
         want = sum(s[1][n].double() for s in singles)
@@ -80,7 +80,7 @@ def test_batch_equals_single_view_per_view_and_sums(K, precomp, bits):
     # bit-reproducible
     bc2, g2, _, _, _ = _run(K, cams, sc, deg, precomp=precomp, record_bits=bits)
     import torch
-    assert torch.equal(bc.bucket, bc2.bucket) and torch.equal(g["mean2D"], g2["mean2D"])
+    assert torch.equal(bc.bucket, bc2.bucket) and torch.equal(g["mean2D"], g2["mean2D"])  # run to run: identical bits
 
 
 def test_batch_cfg4_window_vs_oracle():
