@@ -104,6 +104,39 @@ __device__ __forceinline__ float3 sh_backward(int deg, int M, float3 pos, float3
   return dnormvdv(dorig, ddir);
 }
 
+// dL/dSigma (6-vector, off-diagonals doubled) -> dL/dscale, dL/drot  (backward.cu:426-489): Sigma = R S^2 R^T.
+__device__ __forceinline__ void cov3d_backward(const float (&gcov)[6], float3 sc, float4 q, float scale_modifier, float3 &o_scale,
+                                               float4 &o_rot) {
+  const float r = q.x, x = q.y, y = q.z, z = q.w;
+  const float R[3][3] = {{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
+                         {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
+                         {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}};
+  const float s[3] = {scale_modifier * sc.x, scale_modifier * sc.y, scale_modifier * sc.z};
+  const float dS[3][3] = {{gcov[0], 0.5f * gcov[1], 0.5f * gcov[2]},
+                          {0.5f * gcov[1], gcov[3], 0.5f * gcov[4]},
+                          {0.5f * gcov[2], 0.5f * gcov[4], gcov[5]}};
+  float dA[3][3];  // A = S R^T, dL/dA = 2 A dSigma
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int cc = 0; cc < 3; cc++)
+      dA[i][cc] = 2.0f * ((s[i] * R[0][i]) * dS[0][cc] + (s[i] * R[1][i]) * dS[1][cc] + (s[i] * R[2][i]) * dS[2][cc]);
+  o_scale.x = R[0][0] * dA[0][0] + R[1][0] * dA[0][1] + R[2][0] * dA[0][2];
+  o_scale.y = R[0][1] * dA[1][0] + R[1][1] * dA[1][1] + R[2][1] * dA[1][2];
+  o_scale.z = R[0][2] * dA[2][0] + R[1][2] * dA[2][1] + R[2][2] * dA[2][2];
+  float gR[3][3];  // dL/dR[j][i] = s_i dA[i][j]
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) gR[j][i] = s[i] * dA[i][j];
+  float4 dq;
+  dq.x = 2 * z * (gR[1][0] - gR[0][1]) + 2 * y * (gR[0][2] - gR[2][0]) + 2 * x * (gR[2][1] - gR[1][2]);
+  dq.y = 2 * y * (gR[0][1] + gR[1][0]) + 2 * z * (gR[0][2] + gR[2][0]) + 2 * r * (gR[2][1] - gR[1][2]) - 4 * x * (gR[2][2] + gR[1][1]);
+  dq.z = 2 * x * (gR[0][1] + gR[1][0]) + 2 * r * (gR[0][2] - gR[2][0]) + 2 * z * (gR[2][1] + gR[1][2]) - 4 * y * (gR[2][2] + gR[0][0]);
+  dq.w = 2 * r * (gR[1][0] - gR[0][1]) + 2 * x * (gR[0][2] + gR[2][0]) + 2 * y * (gR[2][1] + gR[1][2]) - 4 * z * (gR[1][1] + gR[0][0]);
+  o_rot = dq;
+}
+
 // Everything one Gaussian contributes for ONE view, from the reverse compositor's sums (s0, s1, s2 = the 10 partials) to
 // dL/d{mean3D, cov3D, scale, rotation, SH} and the 6 pose components -- shared by the single-view and the batched kernel so
 // that both produce the same bits per view.  p.viewmatrix / projmatrix / campos are that view's.
@@ -236,36 +269,7 @@ __device__ __forceinline__ void gaussian_chain(const BwdParams &p, float3 mean, 
   }
   o.m2x = g2x; o.m2y = g2y; o.ca = gcx; o.cb = gcy; o.cc = gcz; o.op = gop; o.col = gcol; o.dz = gz; o.gm = gm;
   // ---- 6. cov3D -> scale, rotation ----
-  if (p.scales && want_scale_rot) {  // (skipped in pose-only mode)
-    const float r = q.x, x = q.y, y = q.z, z = q.w;
-    const float R[3][3] = {{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
-                           {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
-                           {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}};
-    const float s[3] = {p.scale_modifier * sc.x, p.scale_modifier * sc.y, p.scale_modifier * sc.z};
-    const float dS[3][3] = {{gcov[0], 0.5f * gcov[1], 0.5f * gcov[2]},
-                            {0.5f * gcov[1], gcov[3], 0.5f * gcov[4]},
-                            {0.5f * gcov[2], 0.5f * gcov[4], gcov[5]}};
-    float dA[3][3];  // A = S R^T, dL/dA = 2 A dSigma
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-      for (int cc = 0; cc < 3; cc++)
-        dA[i][cc] = 2.0f * ((s[i] * R[0][i]) * dS[0][cc] + (s[i] * R[1][i]) * dS[1][cc] + (s[i] * R[2][i]) * dS[2][cc]);
-    o.scale.x = R[0][0] * dA[0][0] + R[1][0] * dA[0][1] + R[2][0] * dA[0][2];
-    o.scale.y = R[0][1] * dA[1][0] + R[1][1] * dA[1][1] + R[2][1] * dA[1][2];
-    o.scale.z = R[0][2] * dA[2][0] + R[1][2] * dA[2][1] + R[2][2] * dA[2][2];
-    float gR[3][3];  // dL/dR[j][i] = s_i dA[i][j]
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-      for (int j = 0; j < 3; j++) gR[j][i] = s[i] * dA[i][j];
-    float4 dq;
-    dq.x = 2 * z * (gR[1][0] - gR[0][1]) + 2 * y * (gR[0][2] - gR[2][0]) + 2 * x * (gR[2][1] - gR[1][2]);
-    dq.y = 2 * y * (gR[0][1] + gR[1][0]) + 2 * z * (gR[0][2] + gR[2][0]) + 2 * r * (gR[2][1] - gR[1][2]) - 4 * x * (gR[2][2] + gR[1][1]);
-    dq.z = 2 * x * (gR[0][1] + gR[1][0]) + 2 * r * (gR[0][2] - gR[2][0]) + 2 * z * (gR[2][1] + gR[1][2]) - 4 * y * (gR[2][2] + gR[0][0]);
-    dq.w = 2 * r * (gR[1][0] - gR[0][1]) + 2 * x * (gR[0][2] + gR[2][0]) + 2 * y * (gR[2][1] + gR[1][2]) - 4 * z * (gR[1][1] + gR[0][0]);
-    o.rot = dq;
-  }
+  if (p.scales && want_scale_rot) cov3d_backward(gcov, sc, q, p.scale_modifier, o.scale, o.rot);
 }
 
 // SHW = 3*M as a compile-time constant (0: runtime) -- the staging loops divide by it per element
@@ -516,7 +520,7 @@ int launch_gaussian_backward(const BwdParams &p, const GeomWS &g, const BinWS &b
 //    contiguous run by emission slot, a wave's 64 Gaussians one contiguous block -- are streamed through LDS with coalesced
 //    loads and added in emission order (the single-view kernel's gather, on its own so that its two dependent memory round
 //    trips overlap across ~6 waves per SIMD instead of stalling a register-heavy kernel); 48 bytes per Gaussian and view out.
-//  k_gaussian_bwd_batch: one workgroup = 64 Gaussians x NW waves (NW = min(K, 8)), wave w taking views w, w + NW, ...: the
+//  k_gaussian_bwd_batch: one workgroup = 64 Gaussians x NW waves (NW = min(K, 4)), wave w taking views w, w + NW, ...: the
 //    Gaussian's SH block is read ONCE for all K views (staged in LDS, shared by the waves), every wave runs the same
 //    per-Gaussian chain as the single-view kernel (gaussian_chain) on its view's sums, and the views' results are added
 //    into ONE LDS row per Gaussian in VIEW ORDER (the waves take turns) -- fixed order end to end, bit-reproducible.  The
@@ -611,7 +615,7 @@ __global__ __launch_bounds__(256) void k_gather_sums(int P, const int *__restric
   (void)radii0;
 }
 
-#define GBB_MAX_WAVES 8
+#define GBB_MAX_WAVES 4  // measured at K = 8, cfg2: 2 waves 118 us, 4 waves 79 us, 8 waves 94 us (two workgroups per CU overlap their serial phases)
 template <int SHW>
 __global__ __launch_bounds__(GB_BLOCK * GBB_MAX_WAVES) void k_gaussian_bwd_batch(BwdParams p, int K, GeomWS g0, ImageWS im0,
                                                                                  const float4 *__restrict__ inst_grad0,
@@ -650,7 +654,6 @@ __global__ __launch_bounds__(GB_BLOCK * GBB_MAX_WAVES) void k_gaussian_bwd_batch
       sh_in[gi * shs_stride + k] = p.shs[base + e];
     }
   }
-  for (int e = threadIdx.x; e < NW * NACC * CS; e += (int)blockDim.x) meet_all[e] = 0.f;
   __syncthreads();
   const float *vm0 = p.viewmatrix, *pj0 = p.projmatrix, *cam0 = p.campos;
   const int *radii0 = p.radii;
@@ -681,7 +684,8 @@ __global__ __launch_bounds__(GB_BLOCK * GBB_MAX_WAVES) void k_gaussian_bwd_batch
       const float4 s0 = g.gsum[3 * ii + 0], s1 = g.gsum[3 * ii + 1], s2 = g.gsum[3 * ii + 2];
       float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       if (vis) {
-        gaussian_chain<true>(p, mean, c6, sc, q, cl, s0, s1, s2, sh_in + tid * shs_stride, shw, p.scales != nullptr, o, tau);
+        // (dL/dscale, dL/drot are linear in dL/dcov3D with view-independent coefficients: formed ONCE below from the sum over views)
+        gaussian_chain<true>(p, mean, c6, sc, q, cl, s0, s1, s2, sh_in + tid * shs_stride, shw, false, o, tau);
         gmask[0] = cl[0] ? 0.f : o.col.x; gmask[1] = cl[1] ? 0.f : o.col.y; gmask[2] = cl[2] ? 0.f : o.col.z;
       }
       // per-view outputs
@@ -706,13 +710,13 @@ __global__ __launch_bounds__(GB_BLOCK * GBB_MAX_WAVES) void k_gaussian_bwd_batch
     }
     // ---- this view is added to the wave's private sums (no other wave touches them) ----
     if (v < K) {
-#define MADD(k, x) mine[(k) * CS] += (x)
+      const bool first_view = v0 == 0;  // (every wave has a view in the first round: NW <= K) stores instead of adds: no zero fill
+#define MADD(k, x) mine[(k) * CS] = first_view ? (x) : mine[(k) * CS] + (x)
       MADD(0, o.op);
       MADD(1, o.gm.x); MADD(2, o.gm.y); MADD(3, o.gm.z);
 #pragma unroll
       for (int k = 0; k < 6; k++) MADD(4 + k, o.cov[k]);
-      MADD(10, o.scale.x); MADD(11, o.scale.y); MADD(12, o.scale.z);
-      MADD(13, o.rot.x); MADD(14, o.rot.y); MADD(15, o.rot.z); MADD(16, o.rot.w);
+      MADD(10, 0.f); MADD(11, 0.f); MADD(12, 0.f); MADD(13, 0.f); MADD(14, 0.f); MADD(15, 0.f); MADD(16, 0.f);  // (unused slots)
 #pragma unroll
       for (int k = 0; k < MC; k++) {
         MADD(17 + 3 * k, shw[k] * gmask[0]);
@@ -763,8 +767,14 @@ __global__ __launch_bounds__(GB_BLOCK * GBB_MAX_WAVES) void k_gaussian_bwd_batch
 #pragma unroll
     for (int k = 0; k < 6; k++) p.dL_dcov3D[6 * i + k] = MGET(4 + k);
     if (p.scales) {
-      p.dL_dscale[3 * i] = MGET(10); p.dL_dscale[3 * i + 1] = MGET(11); p.dL_dscale[3 * i + 2] = MGET(12);
-      reinterpret_cast<float4 *>(p.dL_drot)[i] = make_float4(MGET(13), MGET(14), MGET(15), MGET(16));
+      float gcov[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) gcov[k] = MGET(4 + k);
+      float3 dscale;
+      float4 drot;
+      cov3d_backward(gcov, sc, q, p.scale_modifier, dscale, drot);
+      p.dL_dscale[3 * i] = dscale.x; p.dL_dscale[3 * i + 1] = dscale.y; p.dL_dscale[3 * i + 2] = dscale.z;
+      reinterpret_cast<float4 *>(p.dL_drot)[i] = drot;
     }
 #undef MGET
   }
