@@ -47,6 +47,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"])
     ap.add_argument("--views", type=int, default=8, help="keyframes per mapping window (per rank), each with its own camera")
+    ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
+                    help="HIP streams the window's views are spread over (2: two view groups, the accumulating per-Gaussian chains stay "
+                         "ordered; measured SLOWER than 1 at cfg2, K = 8: 1.10 vs 1.03 ms -- the batched grids already fill the chip)")
+    ap.add_argument("--skip-single", action="store_true", help="profiling runs: only the batched window, no single-view pass")
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -109,7 +113,8 @@ def main():
     geo = dict(sh_degree=deg, shs=shs, scales=scales, rotations=rots)
 
     # two gradient buckets: the all-reduce of step i (RCCL stream) overlaps the kernels of step i+1
-    ctx = BatchContext(K, P, W, H, M, dev, record_bits=bits, grad_slots=2 if world > 1 else 1, n_windows=world, window=rank)
+    ctx = BatchContext(K, P, W, H, M, dev, record_bits=bits, grad_slots=2 if world > 1 else 1, n_windows=world, window=rank,
+                       streams=a.streams)
     pending = [None, None]
     counter = [0]
 
@@ -159,22 +164,23 @@ def main():
 
     # one frame at a time through the single-view entry points: the latency of a sequential tracking loop
     fc = FrameContext(P, W, H, M, dev, record_bits=bits)
-    n_single = max(a.steps, 20)
+    n_single = 0 if a.skip_single else max(a.steps, 20)
 
     def single(n):
         k = n % K
         fc.forward(bg, means, opac, views[k], projs[k], campos[k], tx, ty, sync=(n < K), **geo)
         fc.backward(bg, means, views[k], projs[k], proj_raw, campos[k], tx, ty, dLc[k], dLd[k], **geo)
 
-    for n in range(K):  # every camera once, synchronously: sizes the arena for the largest view
+    for n in range(K if n_single else 0):  # every camera once, synchronously: sizes the arena for the largest view
         single(n)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for n in range(K, K + n_single):
         single(n)
     torch.cuda.synchronize(dev)
-    elapsed_single = time.perf_counter() - t0
-    fc.status()
+    elapsed_single = max(time.perf_counter() - t0, 1e-9)
+    if n_single:
+        fc.status()
     with profile_stages(max_records=n_single * 16) as prof1:
         for n in range(K, K + n_single):
             single(n)
@@ -227,7 +233,7 @@ def main():
                        "views_per_step": K, "ms_per_frame": ms_step / K, "interactions_per_step_rank0": inter, "num_rendered_per_step_rank0": R,
                        "parallelism": ("1 window of %d keyframes per GPU; ONE async all-reduce of a %d-float bucket per step (per-Gaussian grads "
                                        "+ pose-gradient rows), overlapped with the next step" % (K, ctx.buckets[0].numel())) if world > 1
-                       else "single GPU, one HIP stream, batched launches (grids x %d views)" % K},
+                       else "single GPU, batched launches (grids x views), the window's %d views in %d group(s) on %d HIP stream(s)" % (K, a.streams, a.streams)},
             "roofline": {"bound": "valu", "kernel": "k_render_bwd", "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / PEAK_FP32_TFLOPS, "traffic": traffic_of(bwd_pmc),
                          "traffic_unit": "bytes/launch (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes; quoted only if the "
@@ -246,7 +252,7 @@ def main():
                 "k_tile_sort_records": hbm("k_tile_sort_records", "tile_sort_records", sort_bytes),
                 "k_gaussian_bwd_batch": hbm("k_gaussian_bwd_batch", "gaussian_bwd", gb_bytes)},
             "stage_ms_per_step": {k: v / a.steps for k, v in prof.ms.items() if prof.launches[k]},
-            "single_stream": {"ms_per_frame": 1e3 * elapsed_single / n_single, "value_rank0": inter_1 * n_single / elapsed_single,
+            "single_stream": None if not n_single else {"ms_per_frame": 1e3 * elapsed_single / n_single, "value_rank0": inter_1 * n_single / elapsed_single,
                               "stage_ms_per_frame": {k: v / n_single for k, v in prof1.ms.items() if prof1.launches[k]},
                               "k_render_bwd_frac": FLOP_BWD * inter_1 / t1_bwd / 1e12 / PEAK_FP32_TFLOPS if t1_bwd > 0 else 0.0,
                               "k_render_fwd_frac": FLOP_FWD * inter_1 / t1_fwd / 1e12 / PEAK_FP32_TFLOPS if t1_fwd > 0 else 0.0,

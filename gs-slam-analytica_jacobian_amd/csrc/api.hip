@@ -379,7 +379,8 @@ int gsaj_rasterize_backward_batch(int K, int P, int D, int M, int capacity, cons
                                   float tanfovy, const int *radii, void *geom_ws, void *binning_ws, void *image_ws,
                                   const float *dL_dpix, const float *dL_dpix_depth, float *dL_dmean2D, float *dL_dconic,
                                   float *dL_dopacity, float *dL_dcolor, float *dL_ddepth, float *dL_dmean3D, float *dL_dcov3D,
-                                  float *dL_dsh, float *dL_dscale, float *dL_drot, float *dL_dtau, float *dL_dtau_sum, void *stream) {
+                                  float *dL_dsh, float *dL_dscale, float *dL_drot, float *dL_dtau, float *dL_dtau_sum, int flags,
+                                  void *stream) {
   if (K <= 0 || P <= 0 || capacity <= 0 || W <= 0 || H <= 0 || !bg || !means3D || !viewmatrices || !projmatrices || !projmatrix_raw ||
       !radii || !geom_ws || !binning_ws || !image_ws || !dL_dpix || !dL_dpix_depth || !dL_dopacity || !dL_dmean3D || !dL_dcov3D ||
       !dL_dtau_sum) {
@@ -396,7 +397,11 @@ int gsaj_rasterize_backward_batch(int K, int P, int D, int M, int capacity, cons
   if (rc != GSAJ_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-  if ((rc = launch_render_backward(capacity, W, H, gx, gy, bg, b, im, dL_dpix, dL_dpix_depth, K, vs, s)) != GSAJ_OK) return rc;
+  if (!(flags & GSAJ_BWD_ONLY_CHAIN)) {
+    if ((rc = launch_render_backward(capacity, W, H, gx, gy, bg, b, im, dL_dpix, dL_dpix_depth, K, vs, s)) != GSAJ_OK) return rc;
+    if ((rc = launch_gather_sums(P, K, radii, g, b, im, vs, s)) != GSAJ_OK) return rc;
+  }
+  if (flags & GSAJ_BWD_ONLY_COMPOSITE) return GSAJ_OK;
   BwdParams p;
   p.P = P; p.D = D; p.M = M; p.W = W; p.H = H;
   p.means3D = means3D; p.shs = shs; p.scales = scales; p.rotations = rotations;
@@ -411,7 +416,7 @@ int gsaj_rasterize_backward_batch(int K, int P, int D, int M, int capacity, cons
   p.dL_ddepth = dL_ddepth; p.dL_dmean3D = dL_dmean3D; p.dL_dcov3D = dL_dcov3D; p.dL_dsh = dL_dsh;
   p.dL_dscale = dL_dscale; p.dL_drot = dL_drot; p.dL_dtau = dL_dtau; p.dL_dtau_sum = dL_dtau_sum;
   (void)colors_precomp;
-  return launch_gaussian_backward_batch(p, K, g, b, im, vs, s);
+  return launch_gaussian_backward_batch(p, K, g, b, im, vs, (flags & GSAJ_BWD_ACCUMULATE) ? 1 : 0, s);
 }
 
 int gsaj_rasterize_backward(int P, int D, int M, int R, const float *bg, int W, int H, const float *means3D,

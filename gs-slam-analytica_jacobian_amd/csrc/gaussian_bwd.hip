@@ -622,7 +622,7 @@ __global__ __launch_bounds__(GB_BLOCK * GBB_MAX_WAVES) void k_gaussian_bwd_batch
                                                                                  const uint8_t *__restrict__ reached0, ViewStrides vs,
                                                                                  float *__restrict__ pv_mean2D, float *__restrict__ pv_conic,
                                                                                  float *__restrict__ pv_color, float *__restrict__ pv_depth,
-                                                                                 float *__restrict__ pv_tau) {
+                                                                                 float *__restrict__ pv_tau, int accumulate) {
   constexpr int NACC = 17 + SHW;  // opacity, mean3D 3, cov3D 6, scale 3, rot 4, dL/dSH
   constexpr int MC = SHW / 3;     // SH coefficients stored
   constexpr int shs_stride = SHW + 1;
@@ -761,21 +761,27 @@ __global__ __launch_bounds__(GB_BLOCK * GBB_MAX_WAVES) void k_gaussian_bwd_batch
   // ---- outputs, once per Gaussian ----
   if (wave == 0 && idx < p.P) {
 #define MGET(k) meet_all[(k) * CS + tid]
+    // accumulate: this call's sums are ADDED to what the buffers hold (a window processed in several calls, or keyframes of several
+    // windows accumulated on one rank before the optimiser step: callers add in a fixed order, so the result stays reproducible)
+#define OUT(dst, x) dst = accumulate ? dst + (x) : (x)
     const size_t i = (size_t)idx;
-    p.dL_dopacity[i] = MGET(0);
-    p.dL_dmean3D[3 * i] = MGET(1); p.dL_dmean3D[3 * i + 1] = MGET(2); p.dL_dmean3D[3 * i + 2] = MGET(3);
+    OUT(p.dL_dopacity[i], MGET(0));
+    OUT(p.dL_dmean3D[3 * i], MGET(1)); OUT(p.dL_dmean3D[3 * i + 1], MGET(2)); OUT(p.dL_dmean3D[3 * i + 2], MGET(3));
 #pragma unroll
-    for (int k = 0; k < 6; k++) p.dL_dcov3D[6 * i + k] = MGET(4 + k);
+    for (int k = 0; k < 6; k++) OUT(p.dL_dcov3D[6 * i + k], MGET(4 + k));
     if (p.scales) {
       float gcov[6];
 #pragma unroll
-      for (int k = 0; k < 6; k++) gcov[k] = MGET(4 + k);
+      for (int k = 0; k < 6; k++) gcov[k] = MGET(4 + k);  // (this call's part: dL/dscale, dL/drot are linear in it)
       float3 dscale;
       float4 drot;
       cov3d_backward(gcov, sc, q, p.scale_modifier, dscale, drot);
-      p.dL_dscale[3 * i] = dscale.x; p.dL_dscale[3 * i + 1] = dscale.y; p.dL_dscale[3 * i + 2] = dscale.z;
-      reinterpret_cast<float4 *>(p.dL_drot)[i] = drot;
+      OUT(p.dL_dscale[3 * i], dscale.x); OUT(p.dL_dscale[3 * i + 1], dscale.y); OUT(p.dL_dscale[3 * i + 2], dscale.z);
+      float4 *dr = reinterpret_cast<float4 *>(p.dL_drot) + i;
+      if (accumulate) { const float4 o4 = *dr; drot.x += o4.x; drot.y += o4.y; drot.z += o4.z; drot.w += o4.w; }
+      *dr = drot;
     }
+#undef OUT
 #undef MGET
   }
   if (SHW > 0 && p.dL_dsh) {  // coalesced store of the [64][M*3] block (coefficients above the active degree stay zero)
@@ -783,13 +789,15 @@ __global__ __launch_bounds__(GB_BLOCK * GBB_MAX_WAVES) void k_gaussian_bwd_batch
     const int count = min(GB_BLOCK, p.P - blockIdx.x * GB_BLOCK) * SHW;
     for (int e = threadIdx.x; e < count; e += (int)blockDim.x) {
       const int gi = e / (SHW > 0 ? SHW : 1), k = e - gi * SHW;
-      p.dL_dsh[base + e] = meet_all[(17 + k) * CS + gi];
+      const float t = meet_all[(17 + k) * CS + gi];
+      p.dL_dsh[base + e] = accumulate ? p.dL_dsh[base + e] + t : t;
     }
   }
 }
 
 template <int SHW>
-static void launch_gbb(const BwdParams &p, int K, const GeomWS &g, const BinWS &b, const ImageWS &im, ViewStrides vs, hipStream_t s) {
+static void launch_gbb(const BwdParams &p, int K, const GeomWS &g, const BinWS &b, const ImageWS &im, ViewStrides vs, int accumulate,
+                       hipStream_t s) {
   const int nblk = (p.P + GB_BLOCK - 1) / GB_BLOCK;
   const int nw = K < GBB_MAX_WAVES ? K : GBB_MAX_WAVES;
   const size_t sh_floats = ((size_t)GB_BLOCK * (SHW + 1) + 3) & ~(size_t)3;
@@ -797,22 +805,25 @@ static void launch_gbb(const BwdParams &p, int K, const GeomWS &g, const BinWS &
   const size_t lds = sizeof(float) * (sh_floats + meet);
   (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gaussian_bwd_batch<SHW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k_gaussian_bwd_batch<SHW>, dim3(nblk), dim3(GB_BLOCK * nw), lds, s, p, K, g, im, b.inst_grad, b.reached, vs,
-                     p.dL_dmean2D, p.dL_dconic, p.dL_dcolor, p.dL_ddepth, p.dL_dtau);
+                     p.dL_dmean2D, p.dL_dconic, p.dL_dcolor, p.dL_ddepth, p.dL_dtau, accumulate);
+}
+
+int launch_gather_sums(int P, int K, const int *radii, const GeomWS &g, const BinWS &b, const ImageWS &im, ViewStrides vs, hipStream_t s) {
+  GsajProfScope ps(ST_GATHER_SUMS, s);
+  hipLaunchKernelGGL(k_gather_sums, dim3((P + 255) / 256, K), dim3(256), 0, s, P, radii, g, im, b.inst_grad, b.reached, vs);
+  GSAJ_HIP_CHECK(hipGetLastError());
+  return GSAJ_OK;
 }
 
 int launch_gaussian_backward_batch(const BwdParams &p, int K, const GeomWS &g, const BinWS &b, const ImageWS &im, ViewStrides vs,
-                                   hipStream_t s) {
-  {
-    GsajProfScope ps(ST_GATHER_SUMS, s);
-    hipLaunchKernelGGL(k_gather_sums, dim3((p.P + 255) / 256, K), dim3(256), 0, s, p.P, p.radii, g, im, b.inst_grad, b.reached, vs);
-  }
+                                   int accumulate, hipStream_t s) {
   GsajProfScope ps(ST_GAUSSIAN_BWD, s);
   switch (p.shs ? p.M : 0) {
-    case 0: launch_gbb<0>(p, K, g, b, im, vs, s); break;
-    case 1: launch_gbb<3>(p, K, g, b, im, vs, s); break;
-    case 4: launch_gbb<12>(p, K, g, b, im, vs, s); break;
-    case 9: launch_gbb<27>(p, K, g, b, im, vs, s); break;
-    case 16: launch_gbb<48>(p, K, g, b, im, vs, s); break;
+    case 0: launch_gbb<0>(p, K, g, b, im, vs, accumulate, s); break;
+    case 1: launch_gbb<3>(p, K, g, b, im, vs, accumulate, s); break;
+    case 4: launch_gbb<12>(p, K, g, b, im, vs, accumulate, s); break;
+    case 9: launch_gbb<27>(p, K, g, b, im, vs, accumulate, s); break;
+    case 16: launch_gbb<48>(p, K, g, b, im, vs, accumulate, s); break;
     default:
       gsaj_set_error("batched backward: SH storage of %d coefficients is not supported (1, 4, 9 or 16)", p.M);
       return GSAJ_ERR_INVALID_ARGUMENT;

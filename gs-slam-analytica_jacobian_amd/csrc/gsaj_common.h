@@ -241,8 +241,9 @@ int launch_gaussian_backward(const BwdParams &p, const GeomWS &g, const BinWS &b
 // dL_dsh, dL_dscale, dL_drot, dL_dopacity: [P, .]); per-view outputs (any may be NULL): dL_dmean2D [K,P,3], dL_dconic [K,P,4],
 // dL_dcolor [K,P,3], dL_ddepth [K,P], dL_dtau [K,P,6]; dL_dtau_sum [K,6].  p.viewmatrix / projmatrix / campos: [K,.];
 // p.radii [K,P].
+int launch_gather_sums(int P, int K, const int *radii, const GeomWS &g, const BinWS &b, const ImageWS &im, ViewStrides vs, hipStream_t s);
 int launch_gaussian_backward_batch(const BwdParams &p, int K, const GeomWS &g, const BinWS &b, const ImageWS &im, ViewStrides vs,
-                                   hipStream_t s);
+                                   int accumulate, hipStream_t s);
 int launch_mark_visible(int P, const float *means3D, const float *viewmatrix, uint8_t *present, hipStream_t s);
 
 // ---- small device helpers -------------------------------------------------------------------

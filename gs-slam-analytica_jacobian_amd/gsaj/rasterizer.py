@@ -380,10 +380,14 @@ class BatchContext:
     all-reduce ships it, tail = the K pose-gradient rows)."""
 
     def __init__(self, K, P, W, H, M, device, has_scales=True, record_bits=32, per_gaussian_tau=False, grad_slots=1,
-                 n_windows=1, window=0):
+                 n_windows=1, window=0, streams=1):
         """n_windows > 1 (multi-GPU: one window per rank): the bucket's tail has a dL/dtau row for every keyframe of every
         window; this context writes the rows of window `window` and keeps the others zero, so that the ONE sum all-reduce of
-        the bucket also gathers the pose gradients of all ranks."""
+        the bucket also gathers the pose gradients of all ranks.
+        streams = 2: the window is processed as two groups of views on two HIP streams -- the per-Gaussian / binning kernels of
+        one group (latency-bound, few workgroups) overlap the compositors of the other; only the two accumulating per-Gaussian
+        chain launches are ordered (GSAJ_BWD_ONLY_COMPOSITE / _ONLY_CHAIN / _ACCUMULATE).  Results are identical to streams = 1
+        up to the order of the final fp32 additions (group 0's sum + group 1's sum)."""
         from .keyframe_shard import bucket_numel, bucket_views
         lib = _lib.load()
         self.lib, self.K, self.P, self.W, self.H, self.M, self.dev = lib, int(K), int(P), int(W), int(H), int(M), torch.device(device)
@@ -411,6 +415,12 @@ class BatchContext:
                                    scale=v.get("scale"), rot=v.get("rot"), tau=torch.zeros((K, P, 6), **f) if per_gaussian_tau else None,
                                    tau_all=v["tau_all"][window * K:(window + 1) * K], tau_every_window=v["tau_all"] if n_windows > 1 else None))
         self.bucket, self.g = self.buckets[0], self.slots[0]
+        # view groups: [(first view, number of views, stream or None = the caller's current stream)]
+        if streams >= 2 and K >= 2:
+            k0 = (K + 1) // 2
+            self.groups = [(0, k0, None), (k0, K - k0, torch.cuda.Stream(self.dev))]
+        else:
+            self.groups = [(0, K, None)]
 
     def _size(self, capacity):
         self.capacity = int(capacity)
@@ -428,15 +438,35 @@ class BatchContext:
             out.append((R.value, mt.value, rc == -3))
         return out
 
+    def _fork(self):
+        """side streams wait for everything the caller's stream has enqueued so far (inputs, the previous step's results)"""
+        cur = torch.cuda.current_stream(self.dev)
+        for _, _, st in self.groups:
+            if st is not None:
+                st.wait_stream(cur)
+        return cur
+
+    def _join(self, cur):
+        for _, _, st in self.groups:
+            if st is not None:
+                cur.wait_stream(st)
+
     def _launch(self, bg, means3D, opacities, viewmatrices, projmatrices, campos, tanfovx, tanfovy, sh_degree, shs, colors_precomp, scales,
                 rotations, cov3D_precomp, scale_modifier):
-        _lib.check(self.lib.gsaj_rasterize_forward_batch(
-            self.K, self.P, int(sh_degree), self.M, _ptr(bg), self.W, self.H, _ptr(means3D), _ptr(shs), _ptr(colors_precomp),
-            _ptr(opacities), _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrices),
-            _ptr(projmatrices), _ptr(campos), float(tanfovx), float(tanfovy), 0, self.color.data_ptr(), self.depth.data_ptr(),
-            self.opacity.data_ptr(), self.radii.data_ptr(), self.n_touched.data_ptr(), self.geom.data_ptr(), self.binning.data_ptr(),
-            self.binning.numel(), self.capacity, self.tile_list_capacity, self.img.data_ptr(), self.flags, _stream(self.dev)),
-            "gsaj_rasterize_forward_batch")
+        HW, P = self.H * self.W, self.P
+        cur = self._fork()
+        for v0, kv, st in self.groups:
+            stream = cur if st is None else st
+            _lib.check(self.lib.gsaj_rasterize_forward_batch(
+                kv, P, int(sh_degree), self.M, _ptr(bg), self.W, self.H, _ptr(means3D), _ptr(shs), _ptr(colors_precomp),
+                _ptr(opacities), _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp),
+                viewmatrices.data_ptr() + 64 * v0, projmatrices.data_ptr() + 64 * v0, None if campos is None else campos.data_ptr() + 12 * v0,
+                float(tanfovx), float(tanfovy), 0, self.color.data_ptr() + 12 * HW * v0, self.depth.data_ptr() + 4 * HW * v0,
+                self.opacity.data_ptr() + 4 * HW * v0, self.radii.data_ptr() + 4 * P * v0, self.n_touched.data_ptr() + 4 * P * v0,
+                self.geom.data_ptr() + self.geom_stride * v0, self.binning.data_ptr() + self.bin_stride * v0, self.bin_stride * kv,
+                self.capacity, self.tile_list_capacity, self.img.data_ptr() + self.img_stride * v0, self.flags, stream.cuda_stream),
+                "gsaj_rasterize_forward_batch")
+        self._join(cur)
 
     def forward(self, bg, means3D, opacities, viewmatrices, projmatrices, campos, tanfovx, tanfovy, sh_degree=0, shs=None,
                 colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, scale_modifier=1.0, sync=True):
@@ -467,14 +497,30 @@ class BatchContext:
         g = self.slots[slot]
         if g["tau_every_window"] is not None:
             g["tau_every_window"].zero_()  # rows of the other ranks' windows must be zero before the sum all-reduce
-        _lib.check(self.lib.gsaj_rasterize_backward_batch(
-            self.K, self.P, int(sh_degree), self.M, self.capacity, _ptr(bg), self.W, self.H, _ptr(means3D), _ptr(shs),
-            _ptr(colors_precomp), _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrices),
-            _ptr(projmatrices), _ptr(projmatrix_raw), _ptr(campos), float(tanfovx), float(tanfovy), self.radii.data_ptr(),
-            self.geom.data_ptr(), self.binning.data_ptr(), self.img.data_ptr(), _ptr(dL_dcolor), _ptr(dL_ddepth),
-            g["mean2D"].data_ptr(), None, g["opacity"].data_ptr(), None, None, g["mean3D"].data_ptr(), g["cov3D"].data_ptr(),
-            _ptr(g["sh"]), _ptr(g["scale"]), _ptr(g["rot"]), _ptr(g["tau"]), g["tau_all"].data_ptr(), _stream(self.dev)),
-            "gsaj_rasterize_backward_batch")
+        HW, P = self.H * self.W, self.P
+
+        def call(v0, kv, stream, flags):
+            _lib.check(self.lib.gsaj_rasterize_backward_batch(
+                kv, P, int(sh_degree), self.M, self.capacity, _ptr(bg), self.W, self.H, _ptr(means3D), _ptr(shs),
+                _ptr(colors_precomp), _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp),
+                viewmatrices.data_ptr() + 64 * v0, projmatrices.data_ptr() + 64 * v0, _ptr(projmatrix_raw),
+                None if campos is None else campos.data_ptr() + 12 * v0, float(tanfovx), float(tanfovy), self.radii.data_ptr() + 4 * P * v0,
+                self.geom.data_ptr() + self.geom_stride * v0, self.binning.data_ptr() + self.bin_stride * v0,
+                self.img.data_ptr() + self.img_stride * v0, dL_dcolor.data_ptr() + 12 * HW * v0, dL_ddepth.data_ptr() + 4 * HW * v0,
+                g["mean2D"].data_ptr() + 12 * P * v0, None, g["opacity"].data_ptr(), None, None, g["mean3D"].data_ptr(),
+                g["cov3D"].data_ptr(), _ptr(g["sh"]), _ptr(g["scale"]), _ptr(g["rot"]),
+                None if g["tau"] is None else g["tau"].data_ptr() + 24 * P * v0, g["tau_all"].data_ptr() + 24 * v0, flags,
+                stream.cuda_stream), "gsaj_rasterize_backward_batch")
+
+        cur = self._fork()
+        if len(self.groups) == 1:
+            call(0, self.K, cur, 0)
+            return g
+        for v0, kv, st in self.groups:      # per-view halves: independent, one stream each
+            call(v0, kv, cur if st is None else st, 2)
+        self._join(cur)                      # the accumulating per-Gaussian chains: in group order on the caller's stream
+        for i, (v0, kv, st) in enumerate(self.groups):
+            call(v0, kv, cur, 4 | (1 if i > 0 else 0))
         return g
 
     def interactions(self):

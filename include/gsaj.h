@@ -196,7 +196,19 @@ int gsaj_rasterize_backward_batch(int K, int P, int D, int M, int capacity, cons
                                   void *binning_ws, void *image_ws, const float *dL_dpix, const float *dL_dpix_depth,
                                   float *dL_dmean2D, float *dL_dconic, float *dL_dopacity, float *dL_dcolor, float *dL_ddepth,
                                   float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh, float *dL_dscale, float *dL_drot,
-                                  float *dL_dtau, float *dL_dtau_sum, void *stream);
+                                  float *dL_dtau, float *dL_dtau_sum, int flags /* GSAJ_BWD_* */, void *stream);
+/* flags of gsaj_rasterize_backward_batch:
+ * GSAJ_BWD_ACCUMULATE      the summed per-Gaussian outputs are ADDED to what their buffers hold instead of overwriting them:
+ *                          a window processed in several calls (views [0,K0) then [K0,K)), or the keyframes of several windows
+ *                          accumulated on one rank before the optimiser step (utils/slam_backend.py:168-232: current window +
+ *                          2 random older keyframes, ONE backward).  Calls add in the caller's order: reproducible.
+ * GSAJ_BWD_ONLY_COMPOSITE  run only the per-view half (reverse compositor + per-Gaussian gather of its partial sums);
+ * GSAJ_BWD_ONLY_CHAIN      run only the per-Gaussian chain on views whose per-view half has already run.
+ *                          Together they let a caller put the per-view halves of two view groups on two HIP streams (they are
+ *                          independent) and serialise only the accumulating chains (gsaj.rasterizer.BatchContext(streams=2)). */
+#define GSAJ_BWD_ACCUMULATE 1
+#define GSAJ_BWD_ONLY_COMPOSITE 2
+#define GSAJ_BWD_ONLY_CHAIN 4
 
 /* ---- frustum test -------------------------------------------------------------------- */
 int gsaj_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix,

@@ -16,7 +16,7 @@ from gsaj import synthetic as syn
 pytestmark = pytest.mark.gpu
 
 
-def _run(K, cams, sc, deg, precomp=False, record_bits=32, seed=50):
+def _run(K, cams, sc, deg, precomp=False, record_bits=32, seed=50, streams=1):
     import torch
     from gsaj.rasterizer import BatchContext, FrameContext
 
@@ -39,7 +39,7 @@ def _run(K, cams, sc, deg, precomp=False, record_bits=32, seed=50):
     seeds = [hp.seeds(c, seed=seed + k) for k, c in enumerate(cams)]
     dLc = t(np.stack([s[0] for s in seeds]))
     dLd = t(np.stack([s[1] for s in seeds]))
-    bc = BatchContext(K, P, W, H, M, dev, has_scales=not precomp, record_bits=record_bits, per_gaussian_tau=True)
+    bc = BatchContext(K, P, W, H, M, dev, has_scales=not precomp, record_bits=record_bits, per_gaussian_tau=True, streams=streams)
     st = bc.forward(bg, means, opac, views, projs, cps, cams[0]["tanfovx"], cams[0]["tanfovy"], sh_degree=deg, **kw)
     g = bc.backward(bg, means, views, projs, praw, cps, cams[0]["tanfovx"], cams[0]["tanfovy"], dLc, dLd, sh_degree=deg, **kw)
     singles = []
@@ -71,14 +71,16 @@ def _compare(bc, g, st, singles, precomp):
         assert e < 3e-5, (n, e)  # K terms, each within the chain's fp32 rounding (cf. */chain_row in parity_errors.jsonl), summed in view order
 
 
-@pytest.mark.parametrize("K,precomp,bits", [(3, False, 32), (5, True, 32), (8, False, 16), (11, False, 32)])
-def test_batch_equals_single_view_per_view_and_sums(K, precomp, bits):
+@pytest.mark.parametrize("K,precomp,bits,streams", [(3, False, 32, 1), (5, True, 32, 2), (8, False, 16, 2), (11, False, 32, 1), (2, False, 32, 2)])
+def test_batch_equals_single_view_per_view_and_sums(K, precomp, bits, streams):
+    """streams = 2: the window as two view groups on two HIP streams, the second group's per-Gaussian sums ACCUMULATED onto the
+    first's (GSAJ_BWD_ONLY_COMPOSITE / _ONLY_CHAIN / _ACCUMULATE)."""
     cam0, sc, deg = hp.make("p6000_640x480_sh1")
     cams = syn.keyframe_cameras(K, W=cam0["W"], H=cam0["H"], fx=cam0["fx"], fy=cam0["fy"], cx=cam0["cx"], cy=cam0["cy"])
-    bc, g, st, singles, _ = _run(K, cams, sc, deg, precomp=precomp, record_bits=bits)
+    bc, g, st, singles, _ = _run(K, cams, sc, deg, precomp=precomp, record_bits=bits, streams=streams)
     _compare(bc, g, st, singles, precomp)
     # bit-reproducible
-    bc2, g2, _, _, _ = _run(K, cams, sc, deg, precomp=precomp, record_bits=bits)
+    bc2, g2, _, _, _ = _run(K, cams, sc, deg, precomp=precomp, record_bits=bits, streams=streams)
     import torch
     assert torch.equal(bc.bucket, bc2.bucket) and torch.equal(g["mean2D"], g2["mean2D"])  # run to run: identical bits
 

@@ -5,7 +5,7 @@ for rep in 1 2; do
 for n in "$@"; do
   lib=$GRAFT_REPO_ROOT/gs-slam-analytica_jacobian_amd/lib/$n/libgsaj_hip.so
   [ "$n" = base ] && lib=$GRAFT_REPO_ROOT/gs-slam-analytica_jacobian_amd/lib/libgsaj_hip.so
-  GSAJ_LIB_PATH=$lib timeout -k 10 120 python bench.py --no-cpu-baseline --steps 40 > gpurun_out/ab_$n.json 2> gpurun_out/ab_$n.err || { echo "$n FAILED"; tail -3 gpurun_out/ab_$n.err; exit 1; }
+  GSAJ_LIB_PATH=$lib timeout -k 10 120 python bench.py --no-cpu-baseline --steps 40 $BENCH_ARGS > gpurun_out/ab_$n.json 2> gpurun_out/ab_$n.err || { echo "$n FAILED"; tail -3 gpurun_out/ab_$n.err; exit 1; }
   python - "$n" <<'PY'
 import json, sys
 d = json.load(open("gpurun_out/ab_%s.json" % sys.argv[1]))

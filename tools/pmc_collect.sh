@@ -5,8 +5,8 @@ set -e
 out=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$out" && rm -rf "$out"/*
-B="python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline $*"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$out/stats" -o run --output-format csv -- python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline "$@" > "$out/bench_under_rocprof.json" 2> "$out/rocprof.err"
+B="python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --skip-single $*"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$out/stats" -o run --output-format csv -- python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline --skip-single "$@" > "$out/bench_under_rocprof.json" 2> "$out/rocprof.err"
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/pmcF" -o run --output-format csv -- $B > /dev/null 2> "$out/pmcF.err"
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$out/pmcW" -o run --output-format csv -- $B > /dev/null 2> "$out/pmcW.err"
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS -d "$out/pmcA" -o run --output-format csv -- $B > /dev/null 2> "$out/pmcA.err"

@@ -39,7 +39,7 @@ def main():
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
     for k, cs in res.items():
-        print(k, {c: round(v, 1) for c, v in cs.items()})
+        print(k, {c: (round(v, 3) if isinstance(v, float) else v) for c, v in cs.items()})
 
 
 if __name__ == "__main__":
