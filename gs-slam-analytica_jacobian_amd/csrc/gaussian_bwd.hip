@@ -525,12 +525,25 @@ int launch_gaussian_backward(const BwdParams &p, const GeomWS &g, const BinWS &b
 //    per-Gaussian chain as the single-view kernel (gaussian_chain) on its view's sums, and the views' results are added
 //    into ONE LDS row per Gaussian in VIEW ORDER (the waves take turns) -- fixed order end to end, bit-reproducible.  The
 //    summed gradients are written once instead of K times; dL/dSH is summed in its factored form w_k(view dir) * g[ch].
+// one step of the keyed wave scan: lanes that receive a value through the DPP pattern CTRL (row mask ROWS) add it iff it comes from
+// the same owner; lanes the pattern does not reach see the key -1 and add nothing
+template <int CTRL, int ROWS>
+__device__ __forceinline__ void scan_by_key_step(int own, float (&v)[10]) {
+  const int own_in = __builtin_amdgcn_update_dpp(-1, own, CTRL, ROWS, 0xF, false);
+  const bool same = own_in == own;
+#pragma unroll
+  for (int c = 0; c < 10; c++) {
+    const float in = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[c]), CTRL, ROWS, 0xF, false));
+    v[c] += same ? in : 0.f;
+  }
+}
+
 // k_gather_sums: lane = ROW.  A wave owns 64 consecutive Gaussians, whose instance rows are ONE contiguous block ordered by
 // owner; it walks the block 64 rows at a time with fully coalesced loads (row + `reached` flag requested together: one memory
 // round trip; the next 64 rows are requested before the current ones are reduced), finds every row's owner by a 6-step binary
 // search over the owners' end slots (lane shuffles), runs a scan-by-key over the 64 rows (Hillis-Steele, add when the owner of
-// lane l equals the owner of lane l - d: exact for contiguous segments), and each owner picks up its segment's total from its
-// segment's last row of the group.  No LDS staging, no per-lane loop over a heavy-tailed run length (that loop kept ~20 % of
+// lane l equals the owner of lane l - d: exact for contiguous segments; DPP, no LDS), and each owner picks up its segment's total
+// from its segment's last row of the group.  No LDS staging, no per-lane loop over a heavy-tailed run length (that loop kept ~20 % of
 // the lanes busy and its scattered ds_read_b128 conflicted 4-way: 100 us; this form: see profiles/).  The additions follow a
 // fixed tree per 64-row group and the groups in order: bit-reproducible.
 __global__ __launch_bounds__(256) void k_gather_sums(int P, const int *__restrict__ radii0, GeomWS g0, ImageWS im0,
@@ -585,17 +598,16 @@ __global__ __launch_bounds__(256) void k_gather_sums(int P, const int *__restric
         const uint32_t e = (uint32_t)__shfl((int)endi, own + step - 1);
         if (e <= r) own += step;
       }
-      // scan by key: after the last step lane l holds the sum of the rows of its owner in [max(segment start, base), r]
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const int own_up = __shfl_up(own, d);
-        const bool same = lane >= d && own_up == own;
-#pragma unroll
-        for (int c = 0; c < 10; c++) {
-          const float up = __shfl_up(v[c], d);
-          v[c] += same ? up : 0.f;
-        }
-      }
+      // scan by key: after the last step lane l holds the sum of the rows of its owner in [max(segment start, base), r].
+      // All in the VALU (DPP): four row_shr steps inside each 16-lane row, then row_bcast:15 (rows 1, 3 take lane 15 / 47) and
+      // row_bcast:31 (rows 2, 3 take lane 31, which by then carries rows 0-1) -- the keyed form of the classic wave scan: a lane
+      // adds the incoming value iff it comes from the same owner, exact because an owner's rows are contiguous.
+      scan_by_key_step<0x111, 0xF>(own, v);  // row_shr:1
+      scan_by_key_step<0x112, 0xF>(own, v);  // row_shr:2
+      scan_by_key_step<0x114, 0xF>(own, v);  // row_shr:4
+      scan_by_key_step<0x118, 0xF>(own, v);  // row_shr:8
+      scan_by_key_step<0x142, 0xA>(own, v);  // row_bcast:15 -> rows 1, 3
+      scan_by_key_step<0x143, 0xC>(own, v);  // row_bcast:31 -> rows 2, 3
       // every owner whose run meets this group takes the total at its run's last row inside the group
       const uint32_t run_lo = max(first, base), run_hi = min(first + cnt, min(base + 64u, E));
       const bool mine = cnt > 0 && run_lo < run_hi;
