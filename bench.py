@@ -181,7 +181,7 @@ def main():
     elapsed_single = max(time.perf_counter() - t0, 1e-9)
     if n_single:
         fc.status()
-    with profile_stages(max_records=n_single * 16) as prof1:
+    with profile_stages(max_records=max(16, n_single * 16)) as prof1:
         for n in range(K, K + n_single):
             single(n)
         torch.cuda.synchronize(dev)
@@ -317,7 +317,7 @@ def cpu_baseline(cam, sc, deg, budget_s):
             reps += 1
             inter += st["interactions"]
             el = time.perf_counter() - t0
-            if el >= budget or reps >= 16:
+            if el >= budget or reps >= 64:
                 break
         orc.set_threads(1)
         return {"value": inter / el, "unit": "interactions/s", "cores": used, "kind": "port",

@@ -72,7 +72,7 @@ static inline __host__ __device__ size_t geom_carve(char *base, size_t P, GeomWS
 
 #define TILE_REP 1        // replicas of each tile's instance counter (1: contention is removed by LDS aggregation)
 #define LDS_TILES_MAX 8192  // images with more tiles than this bin with direct global atomics
-#define SORT_CAP 4096     // largest tile list the in-LDS tile sort handles; longer lists -> global radix fallback
+#define SORT_CAP 16384    // largest tile list the in-LDS tile sort handles (128 KB of the CU's 160 KB LDS); longer lists -> global radix fallback
 #define N_COUNTERS 64     // frame counters: [0] num_rendered [1] error flags [2] longest tile list [3] tau ticket
                           //   [5] preprocess ticket (last workgroup runs the frame scan)
                           //   [4] abort (async forward: arena too small / tile list too long -> later kernels return)

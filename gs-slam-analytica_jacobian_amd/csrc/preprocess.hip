@@ -685,6 +685,9 @@ int launch_tile_binning(int P, int R, int sort_cap, int rec16, int grid_x, int g
     GsajProfScope ps(ST_TILE_SORT, s);
     int cap = 128;
     while (cap < sort_cap && cap < SORT_CAP) cap <<= 1;
+    if (sizeof(uint64_t) * (size_t)cap > 65536)  // lists of 8193 .. 16384 keys: more dynamic LDS than the 64 KB default limit
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_sort_records), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(sizeof(uint64_t) * (size_t)cap));
     hipLaunchKernelGGL(k_tile_sort_records, dim3(grid_x * grid_y, views), dim3(256), sizeof(uint64_t) * (size_t)cap, s, grid_x, grid_y,
                        radii, features, g, im, b.keys_unsorted, b.point_list, b.records, cap, rec16, vs);
   }

@@ -13,6 +13,7 @@ from . import _lib
 
 _F32 = torch.float32
 FORCE_GLOBAL_SORT = False  # tests flip this to exercise the global radix-sort binning path
+SORT_CAP = 16384  # longest tile list the per-tile LDS sort handles (csrc/gsaj_common.h)
 
 
 def _ptr(t):
@@ -268,7 +269,7 @@ class FrameContext:
         self.binning = torch.empty(0, **byte)
         self.R = 0
         self.capacity = 0  # > 0 once an arena has been sized: enables forward(sync=False)
-        self.tile_list_capacity = 0  # longest tile list asynchronous frames may contain (0: the maximum, 4096)
+        self.tile_list_capacity = 0  # longest tile list asynchronous frames may contain (0: the maximum, 16384)
         # per-Gaussian parameter gradients live in ONE flat bucket (field-major) so that a multi-GPU
         # mapping step can all-reduce it with a single collective (gsaj.keyframe_shard); `grad_slots`
         # buckets let the collective of step i overlap the kernels of step i+1
@@ -337,7 +338,7 @@ class FrameContext:
         self.R, self.max_tile_list = R.value, mt.value
         # asynchronous frames get an LDS sort sized for twice the longest tile list seen so far (a longer list aborts
         # the frame on the device, exactly like an arena overflow: status() raises, forward(sync=True) recovers)
-        self.tile_list_capacity = min(4096, max(self.tile_list_capacity, 2 * self.max_tile_list, 256))
+        self.tile_list_capacity = min(SORT_CAP, max(self.tile_list_capacity, 2 * self.max_tile_list, 256))
         self._ensure_binning(self.R)
         self.true_R = self.R
         _lib.check(lib.gsaj_forward_render(
@@ -483,13 +484,13 @@ class BatchContext:
         st = self.status()
         if any(ab for _, _, ab in st):
             self._size(int(1.5 * max(r for r, _, _ in st)) + 1024)
-            self.tile_list_capacity = 0  # the maximum (4096) until the lists are known
+            self.tile_list_capacity = 0  # the maximum (16384) until the lists are known
             self.img.zero_()
             self._launch(*a)
             st = self.status()
             if any(ab for _, _, ab in st):
-                raise _lib.GsajError("a view needs a tile list longer than the LDS sort handles (4096): use the single-view entry points")
-        self.tile_list_capacity = min(4096, max(self.tile_list_capacity, 2 * max(m for _, m, _ in st), 256))
+                raise _lib.GsajError("a view needs a tile list longer than the LDS sort handles (16384): use the single-view entry points")
+        self.tile_list_capacity = min(SORT_CAP, max(self.tile_list_capacity, 2 * max(m for _, m, _ in st), 256))
         return st
 
     def backward(self, bg, means3D, viewmatrices, projmatrices, projmatrix_raw, campos, tanfovx, tanfovy, dL_dcolor, dL_ddepth,

@@ -117,7 +117,7 @@ int gsaj_rasterize_forward(int P, int D, int M, const float *bg, int W, int H,
  * gsaj_forward_num_rendered -- which may be called at any later time -- returns
  * GSAJ_ERR_WORKSPACE_TOO_SMALL together with the R to size the arena for; the caller then repeats
  * the frame (with a larger arena, or through the synchronising entry points, which also have the
- * global-sort fallback).  tile_list_capacity (0 = the maximum, 4096): the longest tile list the frame may
+ * global-sort fallback).  tile_list_capacity (0 = the maximum, 16384): the longest tile list the frame may
  * contain; the per-tile LDS sort is given exactly that much shared memory, so scenes with short lists keep
  * more workgroups resident.  A frame with a longer list is aborted like one that overflows the arena. */
 int gsaj_rasterize_forward_async(int P, int D, int M, const float *bg, int W, int H,

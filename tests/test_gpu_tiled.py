@@ -222,20 +222,22 @@ def test_dL_dtau_matches_finite_differences(torch_cuda):
     assert np.abs(ana - num).max() < 1e-2 * np.abs(num).max(), (ana, num)
 
 
-@pytest.mark.parametrize("mode", ["forced", "oversized_tile"])
+@pytest.mark.parametrize("mode", ["forced", "long_lists_in_lds", "oversized_tile"])
 def test_global_sort_fallback_path(torch_cuda, mode):
-    """Binning has two paths: per-tile LDS sort (lists <= 4096 entries) and the global radix sort of
-    (tile, depth) keys.  Both must give the oracle's order bit for bit."""
+    """Binning has two paths: per-tile LDS sort (lists <= 16384 entries: up to 128 KB of LDS) and the global radix sort of
+    (tile, depth) keys.  Both must give the oracle's order bit for bit -- also for lists of ~6000 entries, which use more
+    dynamic LDS than the 64 KB default limit, and for lists beyond the LDS capacity."""
     from gsaj import rasterizer as C
     from gsaj import synthetic as syn
     from oracle import oracle as orc
 
     if mode == "forced":
         cam, sc, deg = hp.make("p2000_160x120")
-    else:  # 6000 Gaussians on a 32x32 image: every tile list is longer than the LDS capacity
+    else:  # 6000 / 18000 Gaussians on a 32x32 image: every tile list has ~6000 (LDS, > 64 KB) / > 16384 (fallback) entries
+        n = 6000 if mode == "long_lists_in_lds" else 18000
         cam = hp.small_camera(32, 32, f=30.0, orthonormal=True)
-        sc = syn.make_scene(6000, 9, cam, z_range=(1.0, 3.0), log_scale_range=(np.log(0.2), np.log(0.5)), sh_coeffs=1,
-                            opacity_range=(0.01, 0.05), margin=-0.1)
+        sc = syn.make_scene(n, 9, cam, z_range=(1.0, 3.0), log_scale_range=(np.log(0.2), np.log(0.5)), sh_coeffs=1,
+                            opacity_range=(0.01, 0.05) if n == 6000 else (0.004, 0.02), margin=-0.1)
         deg = 0
     (ref, st), kw = hp.oracle_forward(cam, sc, deg)
     C.FORCE_GLOBAL_SORT = mode == "forced"
@@ -244,8 +246,11 @@ def test_global_sort_fallback_path(torch_cuda, mode):
     finally:
         C.FORCE_GLOBAL_SORT = False
     R, color, radii, geom, binning, img, depth, opacity, n_touched = out
+    longest = (st["ranges"][:, 1] - st["ranges"][:, 0]).max()
+    if mode == "long_lists_in_lds":
+        assert 8192 >= longest > 4096 or 16384 >= longest > 4096
     if mode == "oversized_tile":
-        assert (st["ranges"][:, 1] - st["ranges"][:, 0]).max() > 4096
+        assert longest > 16384
     dbg = {k: v.cpu().numpy() for k, v in C.debug_export(sc["means3D"].shape[0], R, cam["W"], cam["H"], geom, binning, img).items()}
     np.testing.assert_array_equal(dbg["point_list"].astype(np.uint32), st["point_list"])
     np.testing.assert_array_equal(dbg["ranges"], st["ranges"])
@@ -293,7 +298,7 @@ def test_async_forward_matches_sync_and_reports_overflow(torch_cuda):
     ctx2 = FrameContext(P, cam["W"], cam["H"], M, dev)
     ctx2.forward(**args, sync=True)
     longest = ctx2.status()[1]
-    assert ctx2.tile_list_capacity >= 2 * longest or ctx2.tile_list_capacity == 4096
+    assert ctx2.tile_list_capacity >= 2 * longest or ctx2.tile_list_capacity == 16384
     ctx2.forward(**args, sync=False)
     assert torch.equal(ctx2.color, ref[0])
     ctx2.tile_list_capacity = max(1, longest // 2)
