@@ -336,9 +336,11 @@ class FrameContext:
         _lib.check(lib.gsaj_forward_num_rendered(self.W, self.H, self.img.data_ptr(), st, ctypes.byref(R), ctypes.byref(mt)),
                    "gsaj_forward_num_rendered")
         self.R, self.max_tile_list = R.value, mt.value
-        # asynchronous frames get an LDS sort sized for twice the longest tile list seen so far (a longer list aborts
-        # the frame on the device, exactly like an arena overflow: status() raises, forward(sync=True) recovers)
-        self.tile_list_capacity = min(SORT_CAP, max(self.tile_list_capacity, 2 * self.max_tile_list, 256))
+        # asynchronous frames get an LDS sort sized for the longest tile list seen so far + 10 % (the launcher rounds up to a power
+        # of two, which is what the bitonic network pads to anyway; more LDS than that only costs resident workgroups: 2x the
+        # longest list made cfg5's sort 2.2x slower).  A longer list aborts the frame on the device, exactly like an arena
+        # overflow: status() raises, forward(sync=True) recovers
+        self.tile_list_capacity = min(SORT_CAP, max(self.tile_list_capacity, int(1.1 * self.max_tile_list) + 1, 256))
         self._ensure_binning(self.R)
         self.true_R = self.R
         _lib.check(lib.gsaj_forward_render(
@@ -490,7 +492,7 @@ class BatchContext:
             st = self.status()
             if any(ab for _, _, ab in st):
                 raise _lib.GsajError("a view needs a tile list longer than the LDS sort handles (16384): use the single-view entry points")
-        self.tile_list_capacity = min(SORT_CAP, max(self.tile_list_capacity, 2 * max(m for _, m, _ in st), 256))
+        self.tile_list_capacity = min(SORT_CAP, max(self.tile_list_capacity, int(1.1 * max(m for _, m, _ in st)) + 1, 256))
         return st
 
     def backward(self, bg, means3D, viewmatrices, projmatrices, projmatrix_raw, campos, tanfovx, tanfovy, dL_dcolor, dL_ddepth,
