@@ -238,15 +238,16 @@ def main():
                          "frac": ach / PEAK_FP32_TFLOPS, "traffic": traffic_of(bwd_pmc),
                          "traffic_unit": "bytes/launch (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes; quoted only if the "
                                          "committed summary was taken from these kernel sources; algorithmic: %d)" % (R * 96 + K * W * H * 32),
-                         "executed_valu_util": bwd_pmc.get("valu_util") if bwd_pmc.get("csrc_sha1") == csrc_hash() else None,
+                         "executed_valu_util": valu_util(bwd_pmc, t_bwd),
                          "note": "fp32 VALU / transcendental-bound reverse compositor (not MFMA, not HBM): NOTIONAL fraction = 87 fp32 flop x "
                                  "interactions per launch / HIP-event launch time / fp32 vector peak; culling skips most lane-operations, so "
-                                 "executed_valu_util (VALU busy cycles / total, from PMC) is the pipe utilisation",
+                                 "executed_valu_util is the pipe utilisation: SQ_INSTS_VALU (PMC, same kernel sources) x 4 cycles (a wave64 "
+                                 "VALU instruction holds its SIMD at least 4 cycles) / (launch time x 2.4 GHz x 1024 SIMDs)",
                          "avg_launch_ms": t_bwd * 1e3, "launch_covers_views": K},
             "roofline_other": {
                 "k_render_fwd": {"bound": "valu", "achieved": FLOP_FWD * inter / t_fwd / 1e12 if t_fwd > 0 else 0.0, "peak": PEAK_FP32_TFLOPS,
                                  "unit": "TFLOP/s", "frac": FLOP_FWD * inter / t_fwd / 1e12 / PEAK_FP32_TFLOPS if t_fwd > 0 else 0.0,
-                                 "avg_launch_ms": t_fwd * 1e3},
+                                 "avg_launch_ms": t_fwd * 1e3, "executed_valu_util": valu_util((pmc or {}).get("k_render_fwd"), t_fwd)},
                 "k_preprocess": hbm("k_preprocess", "preprocess", pre_bytes),
                 "k_scatter_instances": hbm("k_scatter_instances", "scatter_instances", scat_bytes),
                 "k_tile_sort_records": hbm("k_tile_sort_records", "tile_sort_records", sort_bytes),
@@ -276,6 +277,13 @@ def pmc_summary():
             return json.load(f)
     except (OSError, ValueError):
         return None
+
+
+def valu_util(k, t_launch):
+    """VALU issue utilisation of one launch from the committed PMC summary (only for the same kernel sources)."""
+    if not k or k.get("csrc_sha1") != csrc_hash() or "SQ_INSTS_VALU" not in k or t_launch <= 0:
+        return None
+    return k["SQ_INSTS_VALU"] * 4.0 / (t_launch * 2.4e9 * 1024.0)
 
 
 def traffic_of(k):

@@ -23,8 +23,7 @@ def main():
                     a[1] += 1
     res = {k.replace("void ", "").split("<")[0]: {c: v[0] / v[1] for c, v in sorted(cs.items())} for k, cs in sorted(acc.items())
            if k.startswith(("k_", "void k_"))}
-    # fingerprint of the kernel sources these counters were collected from (bench.py quotes them only for the same sources),
-    # and the executed-VALU utilisation: cycles a SIMD issued a VALU instruction / cycles it had a wave resident
+    # fingerprint of the kernel sources these counters were collected from (bench.py quotes them only for the same sources)
     import hashlib
     import os
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gs-slam-analytica_jacobian_amd", "csrc")
@@ -34,8 +33,6 @@ def main():
             h.update(open(os.path.join(d, f), "rb").read())
     for k, c in res.items():
         c["csrc_sha1"] = h.hexdigest()[:16]
-        if c.get("SQ_BUSY_CYCLES") and c.get("SQ_ACTIVE_INST_VALU") is not None:
-            c["valu_util"] = c["SQ_ACTIVE_INST_VALU"] / (4.0 * c["SQ_BUSY_CYCLES"]) if c["SQ_BUSY_CYCLES"] else None
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
     for k, cs in res.items():
