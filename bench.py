@@ -207,7 +207,8 @@ def main():
         shf = 3 * M * 4
         # algorithmic bytes per launch of the batched kernels (K views), SURVEY 8(d) regime 1
         pre_bytes = K * P * ((12 + 4 + 12 + 16 + shf) + (4 + 8 + 24 + 16 + 12 + 3 + 4 + 4 + 4 + 48))
-        gb_bytes = P * ((12 + 24 + 12 + 16 + shf) + (12 + 4 + 24 + shf + 12 + 16)) + K * P * (4 + 4 + 4 + 3 + 12) + R * (48 + 1)
+        gather_bytes = R * (48 + 1) + K * P * (4 + 4 + 48)  # instance rows + flags in; tiles_touched, offsets in; 48-B sums out
+        chain_bytes = P * ((12 + 24 + 12 + 16 + shf) + (12 + 4 + 24 + shf + 12 + 16)) + K * P * (48 + 4 + 3 + 12)
         scat_bytes = K * P * (4 + 8 + 4 + 4 + 4) + R * 8
         sort_bytes = R * (8 + 4 + (32 if bits == 16 else 48) + 48)
         t_bwd, t_fwd = per_launch(prof, "render_bwd"), per_launch(prof, "render_fwd")
@@ -251,7 +252,10 @@ def main():
                 "k_preprocess": hbm("k_preprocess", "preprocess", pre_bytes),
                 "k_scatter_instances": hbm("k_scatter_instances", "scatter_instances", scat_bytes),
                 "k_tile_sort_records": hbm("k_tile_sort_records", "tile_sort_records", sort_bytes),
-                "k_gaussian_bwd_batch": hbm("k_gaussian_bwd_batch", "gaussian_bwd", gb_bytes)},
+                "k_gather_sums": hbm("k_gather_sums", "gather_sums", gather_bytes),
+                "k_gaussian_bwd_batch": dict(hbm("k_gaussian_bwd_batch", "gaussian_bwd", chain_bytes),
+                                             note="latency / occupancy-bound (213 VGPRs: 2 waves per SIMD, ~1500-instruction chain per "
+                                                  "(view, Gaussian)), not HBM-bound: the fraction is reported for completeness")},
             "stage_ms_per_step": {k: v / a.steps for k, v in prof.ms.items() if prof.launches[k]},
             "single_stream": None if not n_single else {"ms_per_frame": 1e3 * elapsed_single / n_single, "value_rank0": inter_1 * n_single / elapsed_single,
                               "stage_ms_per_frame": {k: v / n_single for k, v in prof1.ms.items() if prof1.launches[k]},

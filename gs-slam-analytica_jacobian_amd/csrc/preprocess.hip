@@ -548,6 +548,7 @@ __global__ __launch_bounds__(256) void k_tile_sort_records(int gx, int gy, const
   // first 28 stages (k = 2..128: every chunk sorted on its own) never touch LDS, and for k >= 256 only the
   // strides >= 128 do (with workgroup barriers), followed by the seven chunk-local stages in registers again.
   const int lane = tid & 63, wave = tid >> 6;
+#ifndef GSAJ_EXP_NOSORT  // (timing experiment: tools/ab_bench.sh)
   for (int chunk = wave; chunk * 128 < m; chunk += 4) {
     const int ia = chunk * 128 + lane, ib = ia + 64;
     uint64_t A = ia < m ? keys[ia] : ~0ull, B = ib < m ? keys[ib] : ~0ull;
@@ -578,6 +579,7 @@ __global__ __launch_bounds__(256) void k_tile_sort_records(int gx, int gy, const
     }
     __syncthreads();
   }
+#endif
 #ifdef GSAJ_BLOCK_TRACE
   tr_c = wall_clock64();
 #endif
@@ -587,6 +589,9 @@ __global__ __launch_bounds__(256) void k_tile_sort_records(int gx, int gy, const
     const uint32_t id = (uint32_t)key;
     const uint32_t k = beg + (uint32_t)i;
     point_list[k] = id;
+#ifdef GSAJ_EXP_NORECORDS
+    continue;
+#endif
     const float4 a = g.splat[3 * (size_t)id + 0], bq = g.splat[3 * (size_t)id + 1], c = g.splat[3 * (size_t)id + 2];
     const uint32_t rp = __float_as_uint(a.z);
     const int x0 = (int)(rp & 1023u), y0 = (int)((rp >> 10) & 1023u), w = (int)(rp >> 20);

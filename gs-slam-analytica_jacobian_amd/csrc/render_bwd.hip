@@ -121,8 +121,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     if (tid < n) {
       float4 q0, q1, q2;
       gsaj_load_record(records, nullptr, (size_t)(lo + tid), rec16, q0, q1, q2);
+      // the conic is staged PRE-SCALED for v_exp_f32 (gsaj_prescale_conic), like the forward's packed records: the per-entry loop
+      // below then spends no instructions on it; phase 2 (once per 8 entries) scales back
+      const float3 kq = gsaj_prescale_conic(q1.x, q1.y, q1.z);
       rec[tid * REC_F4 + 0] = q0;
-      rec[tid * REC_F4 + 1] = q1;
+      rec[tid * REC_F4 + 1] = make_float4(kq.x, kq.y, kq.z, q1.w);
       rec[tid * REC_F4 + 2] = q2;
     }
     {
@@ -138,7 +141,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
       if (lane < n && first_idx + (uint32_t)lane < wmax) {
         const float4 q0 = rec[lane * REC_F4 + 0];
         const float4 q1 = rec[lane * REC_F4 + 1];
-        rel = quadrant_relevant(q0.x, q0.y, q1.x, q1.y, q1.z, q1.w, qx0, qy0);
+        // (conic back from its pre-scaled form: a = -2/log2e kx, b = -1/log2e ky, c = -2/log2e kz)
+        rel = quadrant_relevant(q0.x, q0.y, (-2.0f / GSAJ_LOG2E) * q1.x, (-1.0f / GSAJ_LOG2E) * q1.y, (-2.0f / GSAJ_LOG2E) * q1.z, q1.w, qx0, qy0);
       }
       unsigned long long todo = __builtin_amdgcn_ballot_w64(rel);
       int nslot = 0;      // accepted entries waiting in wu[] (wave-uniform)
@@ -152,7 +156,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         // slots never mix, and only live ones are stored.
         const int j = __shfl(slot_entry, p2_slot);
         const float4 e0 = rec[j * REC_F4 + 0];
-        const float4 e1 = rec[j * REC_F4 + 1];
+        float4 e1 = rec[j * REC_F4 + 1];
+        e1.x *= -2.0f / GSAJ_LOG2E; e1.y *= -1.0f / GSAJ_LOG2E; e1.z *= -2.0f / GSAJ_LOG2E;  // pre-scaled conic -> (a, b, c)
         const float ax = e0.x - (qx0 + 3.5f), dy = e0.y - p2_py;
         float m0 = 0.f, m1 = 0.f, m2 = 0.f, u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f;
 #pragma unroll
@@ -218,8 +223,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
           }
           const float dx = r0.x - pxf, dy = r0.y - pyf;
           // the forward's own expression (gsaj_common.h): both passes decide power <= 0 / alpha >= 1/255 on identical bits
-          const float3 kc = gsaj_prescale_conic(r1.x, r1.y, r1.z);
-          const float p2 = gsaj_power2(dx, dy, kc.x, kc.y, kc.z);
+          const float p2 = gsaj_power2(dx, dy, r1.x, r1.y, r1.z);
           const float G0 = __builtin_amdgcn_exp2f(p2);
           const float alpha0 = fminf(0.99f, r1.w * G0);
           const bool valid = idx < last && p2 <= 0.0f && alpha0 >= (1.0f / 255.0f);

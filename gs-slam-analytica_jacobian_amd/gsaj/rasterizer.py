@@ -316,6 +316,12 @@ class FrameContext:
         """sync=True: read R back (16-byte D2H, the reference's only sync) and size the arena exactly.
         sync=False: no host round trip at all -- the arena sized by an earlier synchronous frame (x1.5)
         is reused and an overflowing frame aborts on the device; call status() when convenient."""
+        with torch.cuda.device(self.dev):
+            return self._forward(bg, means3D, opacities, viewmatrix, projmatrix, campos, tanfovx, tanfovy, sh_degree, shs, colors_precomp,
+                                 scales, rotations, cov3D_precomp, scale_modifier, sync)
+
+    def _forward(self, bg, means3D, opacities, viewmatrix, projmatrix, campos, tanfovx, tanfovy, sh_degree, shs, colors_precomp, scales,
+                 rotations, cov3D_precomp, scale_modifier, sync):
         lib, st = self.lib, _stream(self.dev)
         if not sync and self.capacity > 0:
             _lib.check(lib.gsaj_rasterize_forward_async(
@@ -357,6 +363,13 @@ class FrameContext:
         g = self.slots[slot]
         if g["tau_all"] is not None:
             g["tau_all"].zero_()  # rows of the other ranks' keyframes must be zero before the sum all-reduce
+        with torch.cuda.device(self.dev):
+            self._backward(g, bg, means3D, viewmatrix, projmatrix, projmatrix_raw, campos, tanfovx, tanfovy, dL_dcolor, dL_ddepth, sh_degree,
+                           shs, colors_precomp, scales, rotations, cov3D_precomp, scale_modifier, pose_only)
+        return g
+
+    def _backward(self, g, bg, means3D, viewmatrix, projmatrix, projmatrix_raw, campos, tanfovx, tanfovy, dL_dcolor, dL_ddepth, sh_degree,
+                  shs, colors_precomp, scales, rotations, cov3D_precomp, scale_modifier, pose_only):
         _lib.check(self.lib.gsaj_rasterize_backward(
             self.P, int(sh_degree), self.M, self.R, _ptr(bg), self.W, self.H, _ptr(means3D), _ptr(shs),
             _ptr(colors_precomp), _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp),

@@ -85,6 +85,18 @@ def test_batch_equals_single_view_per_view_and_sums(K, precomp, bits, streams):
     assert torch.equal(bc.bucket, bc2.bucket) and torch.equal(g["mean2D"], g2["mean2D"])  # run to run: identical bits
 
 
+@pytest.mark.parametrize("P,W,H,K,coeffs", [(1, 33, 17, 1, 1), (65, 47, 31, 3, 4), (257, 129, 65, 6, 9), (1000, 200, 150, 9, 16)])
+def test_batch_ragged_sizes(P, W, H, K, coeffs):
+    """Gaussian counts that are not multiples of the workgroup sizes, odd image sizes, K = 1 and K not a multiple of the waves per
+    workgroup, every SH storage size."""
+    cam0 = hp.small_camera(W, H, f=0.8 * W, orthonormal=True)
+    sc = syn.make_scene(P, 7 + P, cam0, z_range=(0.8, 3.0), log_scale_range=(np.log(0.01), np.log(0.2)), sh_coeffs=coeffs, margin=0.2)
+    cams = syn.keyframe_cameras(K, radius=0.2, W=W, H=H, fx=cam0["fx"], fy=cam0["fy"], cx=cam0["cx"], cy=cam0["cy"])
+    deg = int(round(coeffs ** 0.5)) - 1
+    bc, g, st, singles, _ = _run(K, cams, sc, deg)
+    _compare(bc, g, st, singles, False)
+
+
 def test_batch_cfg4_window_vs_oracle():
     """BASELINE config 4 on one GPU through the batched entry points: 8 TUM-calibrated keyframes, 100 000 Gaussians SH-3."""
     from oracle import oracle as orc
