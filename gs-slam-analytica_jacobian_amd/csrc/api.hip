@@ -208,6 +208,27 @@ int gsaj_forward_aborted_count(int W, int H, const void *image_ws, void *stream,
   return GSAJ_OK;
 }
 
+int gsaj_set_tile_band(int W, int H, void *image_ws, int tile_row_begin, int tile_row_end, void *stream) {
+  const int gy = (H + TILE - 1) / TILE;
+  if (W <= 0 || H <= 0 || !image_ws || tile_row_begin < 0 || tile_row_end < tile_row_begin || tile_row_end > gy || gy > 0xffff) {
+    gsaj_set_error("gsaj_set_tile_band: rows [%d, %d) are not a band of the %d tile rows of a %dx%d frame", tile_row_begin,
+                   tile_row_end, gy, W, H);
+    return GSAJ_ERR_INVALID_ARGUMENT;
+  }
+  ImageWS im;
+  image_carve(align_base(image_ws), W, H, &im);
+  // 0 = the whole frame; an empty band [b, b) with b > 0 is kept as such (the rank renders nothing); [0, 0) cannot be
+  // told from "whole frame" and is refused
+  const bool whole = tile_row_begin == 0 && tile_row_end == gy;
+  if (!whole && tile_row_end == 0) {
+    gsaj_set_error("gsaj_set_tile_band: the empty band [0, 0) cannot be expressed; give an empty band as [b, b) with b > 0");
+    return GSAJ_ERR_INVALID_ARGUMENT;
+  }
+  const uint32_t band = whole ? 0u : ((uint32_t)tile_row_begin | ((uint32_t)tile_row_end << 16));
+  GSAJ_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(im.sticky + 1), (int)band, 1, (hipStream_t)stream));
+  return GSAJ_OK;
+}
+
 int gsaj_forward_render(int P, int R, int max_tile_list, int W, int H, const float *bg, const float *colors_precomp,
                         const int *radii,
                         void *geom_ws, void *binning_ws, size_t binning_ws_bytes, void *image_ws, float *out_color,
@@ -239,7 +260,7 @@ int gsaj_forward_render(int P, int R, int max_tile_list, int W, int H, const flo
   } else {
     // a tile list exceeds the LDS sort capacity (or the caller forces it with max_tile_list < 0):
     // global radix sort of (tile << 32 | depth) keys, as the reference does
-    if ((rc = launch_emit_keys(P, gx, gy, rad, g, b, s)) != GSAJ_OK) return rc;
+    if ((rc = launch_emit_keys(P, gx, gy, rad, g, b, im, s)) != GSAJ_OK) return rc;
     if ((rc = launch_sort(R, 32 + (int)higher_msb((uint32_t)(gx * gy)), b, s)) != GSAJ_OK) return rc;
     if ((rc = launch_ranges_and_records(P, R, gx, gy, rad, features, g, b, im, s)) != GSAJ_OK) return rc;
   }

@@ -41,8 +41,8 @@ int launch_sort(int R, int end_bit, const BinWS &b, hipStream_t s) {
 __global__ __launch_bounds__(256) void k_ranges_records(int R, int gx, int gy, const uint64_t *__restrict__ keys,
                                                         const uint32_t *__restrict__ point_list,
                                                         const int *__restrict__ radii, const float *__restrict__ features,
-                                                        GeomWS g, uint2 *__restrict__ ranges,
-                                                        float4 *__restrict__ records) {
+                                                        GeomWS g, const uint32_t *__restrict__ sticky,
+                                                        uint2 *__restrict__ ranges, float4 *__restrict__ records) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= R) return;
   const uint64_t key = keys[k];
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void k_ranges_records(int R, int gx, int gy, c
   records[(size_t)k * REC_F4 + 0] = make_float4(xy.x, xy.y, depth, __uint_as_float(id));
   records[(size_t)k * REC_F4 + 1] = co;
   int x0, y0, x1, y1;
-  tile_rect(xy.x, xy.y, radii[id], gx, gy, x0, y0, x1, y1);
+  tile_rect(xy.x, xy.y, radii[id], gx, gy, sticky[1], x0, y0, x1, y1);
   const int ty = (int)tile / gx, tx = (int)tile - ty * gx;
   const uint32_t u = g.point_offsets[id] - g.tiles_touched[id] + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
   records[(size_t)k * REC_F4 + 2] = make_float4(features[3 * (size_t)id], features[3 * (size_t)id + 1],
@@ -79,7 +79,7 @@ int launch_ranges_and_records(int P, int R, int grid_x, int grid_y, const int *r
   if (R > 0) {
     GsajProfScope ps(ST_RANGES_RECORDS, s);
     hipLaunchKernelGGL(k_ranges_records, dim3((R + 255) / 256), dim3(256), 0, s, R, grid_x, grid_y, b.keys, b.point_list,
-                       radii, features, g, im.ranges, b.records);
+                       radii, features, g, im.sticky, im.ranges, b.records);
     GSAJ_HIP_CHECK(hipGetLastError());
   }
   return GSAJ_OK;

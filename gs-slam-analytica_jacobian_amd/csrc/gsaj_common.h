@@ -89,7 +89,7 @@ struct ImageWS {  // reference: ImageState, rasterizer_impl.h:46-53
   uint32_t *tile_count;   // [tiles*TILE_REP]         | zeroed by ONE memset per forward
   uint32_t *tile_cursor;  // [tiles*TILE_REP]        -+
   uint32_t *tile_offset;  // [tiles*TILE_REP + 1] exclusive scan of tile_count (tile-major)
-  uint32_t *sticky;       // [16] never zeroed by a forward: [0] number of aborted async forwards
+  uint32_t *sticky;       // [16] never zeroed by a forward: [0] number of aborted async forwards, [1] tile band (tile_rect)
   uint32_t *finish_list;  // [tiles] tile indices in the order their forward workgroups finished (counters[6] = how many)
   size_t zero_bytes;      // bytes from counters to the end of tile_cursor
 };
@@ -214,7 +214,8 @@ int launch_preprocess(const FwdParams &p, int *radii, int *n_touched, const Geom
 // radii: [views, P]; features: colors_precomp [P,3] shared by every view, or NULL = the view's own SH colours (g.rgb)
 int launch_tile_binning(int P, int R, int sort_cap, int rec16, int grid_x, int grid_y, const int *radii, const float *features, const GeomWS &g,
                         const BinWS &b, const ImageWS &im, int views, ViewStrides vs, hipStream_t s);
-int launch_emit_keys(int P, int grid_x, int grid_y, const int *radii, const GeomWS &g, const BinWS &b, hipStream_t s);
+int launch_emit_keys(int P, int grid_x, int grid_y, const int *radii, const GeomWS &g, const BinWS &b, const ImageWS &im,
+                     hipStream_t s);
 int launch_sort(int R, int end_bit, const BinWS &b, hipStream_t s);
 int launch_ranges_and_records(int P, int R, int grid_x, int grid_y, const int *radii, const float *features,
                               const GeomWS &g, const BinWS &b, const ImageWS &im, hipStream_t s);
@@ -259,11 +260,17 @@ __device__ __forceinline__ float4 xform4x4(const float *m, float3 p) {
 // pixel = ((ndc + 1) * S - 1) / 2 in double, as the reference's un-suffixed literals do (auxiliary.h:41-44)
 __device__ __forceinline__ float ndc2pix(float v, int S) { return (float)((((double)v + 1.0) * (double)S - 1.0) * 0.5); }
 
-__device__ __forceinline__ void tile_rect(float px, float py, int r, int gx, int gy, int &x0, int &y0, int &x1, int &y1) {
+// band: the tile rows this frame renders, begin | end << 16 (ImageWS.sticky[1], gsaj_set_tile_band); 0 = all of them.
+// A banded frame clips every Gaussian's tile rectangle to rows [begin, end): tiles outside get empty lists, Gaussians
+// with no tile inside get radius 0, and every per-Gaussian sum covers the band's tiles only (tile-band sharding of one
+// frame over ranks, DESIGN.md "Multi-GPU").
+__device__ __forceinline__ void tile_rect(float px, float py, int r, int gx, int gy, uint32_t band, int &x0, int &y0, int &x1,
+                                          int &y1) {
+  const int ylo = band ? (int)(band & 0xffffu) : 0, yhi = band ? min(gy, (int)(band >> 16)) : gy;
   x0 = min(gx, max(0, (int)((px - (float)r) / (float)TILE)));
-  y0 = min(gy, max(0, (int)((py - (float)r) / (float)TILE)));
+  y0 = min(yhi, max(ylo, (int)((py - (float)r) / (float)TILE)));
   x1 = min(gx, max(0, (int)((px + (float)r + (float)(TILE - 1)) / (float)TILE)));
-  y1 = min(gy, max(0, (int)((py + (float)r + (float)(TILE - 1)) / (float)TILE)));
+  y1 = min(yhi, max(ylo, (int)((py + (float)r + (float)(TILE - 1)) / (float)TILE)));
 }
 // ---- the compositors' alpha, ONE definition for the forward and the reverse pass ----------------------------------
 // power = -(a dx^2 + c dy^2)/2 - b dx dy is evaluated as log2(e) * power from the pre-scaled conic

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__re
         const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
         const float2 pim = make_float2(ndc2pix(p_proj.x, p.W), ndc2pix(p_proj.y, p.H));
         int x0, y0, x1, y1;
-        tile_rect(pim.x, pim.y, (int)my_radius, p.grid_x, p.grid_y, x0, y0, x1, y1);
+        tile_rect(pim.x, pim.y, (int)my_radius, p.grid_x, p.grid_y, im.sticky[1], x0, y0, x1, y1);
         const int area = (x1 - x0) * (y1 - y0);
         if (area != 0) {
           if (!p.colors_precomp) {
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scatter_instances(int P, int gx, 
     const float2 xy = g.means2D[idx];  // requested together with the radius, not after it (latency-bound kernel)
     const float dep = g.depths[idx];
     if (r > 0) {
-      tile_rect(xy.x, xy.y, r, gx, gy, x0, y0, x1, y1);
+      tile_rect(xy.x, xy.y, r, gx, gy, im.sticky[1], x0, y0, x1, y1);
       key = ((uint64_t)__float_as_uint(dep) << 32) | (uint32_t)idx;
     }
   }
@@ -619,7 +619,8 @@ __global__ __launch_bounds__(256) void k_tile_sort_records(int gx, int gy, const
 // One (tile, depth) key + Gaussian id per touched tile, written at the Gaussian's slot range.
 // Also turns point_offsets into the global inclusive scan.
 __global__ __launch_bounds__(PRE_BLOCK) void k_emit_keys(int P, int gx, int gy, const int *__restrict__ radii, GeomWS g,
-                                                         uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+                                                         const uint32_t *__restrict__ sticky, uint64_t *__restrict__ keys,
+                                                         uint32_t *__restrict__ vals) {
   const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
   if (idx >= P) return;
   const uint32_t incl = g.block_sums[blockIdx.x] + g.point_offsets[idx];
@@ -629,7 +630,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_emit_keys(int P, int gx, int gy, 
     uint32_t off = incl - g.tiles_touched[idx];
     const float2 xy = g.means2D[idx];
     int x0, y0, x1, y1;
-    tile_rect(xy.x, xy.y, r, gx, gy, x0, y0, x1, y1);
+    tile_rect(xy.x, xy.y, r, gx, gy, sticky[1], x0, y0, x1, y1);
     const uint32_t dbits = __float_as_uint(g.depths[idx]);
     for (int y = y0; y < y1; y++)
       for (int x = x0; x < x1; x++) {
@@ -700,12 +701,13 @@ int launch_tile_binning(int P, int R, int sort_cap, int rec16, int grid_x, int g
   return GSAJ_OK;
 }
 
-int launch_emit_keys(int P, int grid_x, int grid_y, const int *radii, const GeomWS &g, const BinWS &b, hipStream_t s) {
+int launch_emit_keys(int P, int grid_x, int grid_y, const int *radii, const GeomWS &g, const BinWS &b, const ImageWS &im,
+                     hipStream_t s) {
   const int nblk = (P + PRE_BLOCK - 1) / PRE_BLOCK;
   {
     GsajProfScope ps(ST_EMIT_KEYS, s);
-    hipLaunchKernelGGL(k_emit_keys, dim3(nblk), dim3(PRE_BLOCK), 0, s, P, grid_x, grid_y, radii, g, b.keys_unsorted,
-                       b.vals_unsorted);
+    hipLaunchKernelGGL(k_emit_keys, dim3(nblk), dim3(PRE_BLOCK), 0, s, P, grid_x, grid_y, radii, g, im.sticky,
+                       b.keys_unsorted, b.vals_unsorted);
   }
   GSAJ_HIP_CHECK(hipGetLastError());
   return GSAJ_OK;

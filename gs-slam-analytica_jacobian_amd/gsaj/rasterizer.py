@@ -290,6 +290,13 @@ class FrameContext:
                 tau_all=v.get("tau_all")))
         self.bucket, self.g = self.buckets[0], self.slots[0]
 
+    def set_tile_band(self, tile_row_begin, tile_row_end):
+        """Render only tile rows [begin, end) from now on (gsaj_set_tile_band; gsaj.tile_band_shard): the frame's other
+        pixels come out as background, every gradient is the band's share.  (0, rows) restores the whole frame."""
+        _lib.check(self.lib.gsaj_set_tile_band(self.W, self.H, self.img.data_ptr(), int(tile_row_begin), int(tile_row_end),
+                                               _stream(self.dev)), "gsaj_set_tile_band")
+        self.band = (int(tile_row_begin), int(tile_row_end))
+
     def _ensure_binning(self, R):
         need = self.lib.gsaj_binning_workspace_bytes(R)
         if self.binning.numel() < need:

@@ -132,6 +132,16 @@ int gsaj_rasterize_forward_async(int P, int D, int M, const float *bg, int W, in
 /* Blocking: number of async forwards aborted on the device since the image workspace was zeroed by
  * the caller (the caller zero-fills the image workspace once, when it allocates it). */
 int gsaj_forward_aborted_count(int W, int H, const void *image_ws, void *stream, int *count /*host*/);
+
+/* Tile-band sharding of ONE frame (tracking on several GPUs; no counterpart in the reference, whose rasteriser is
+ * single-device: cuda_rasterizer/rasterizer_impl.cu:224-352 binds every tile of the frame).  Every later forward that uses
+ * this image workspace renders only tile rows [tile_row_begin, tile_row_end) of the (H + 15) / 16 rows: a Gaussian's tile
+ * rectangle (auxiliary.h:46-58 getRect) is clipped to the band, pixels outside it come out as background / zero depth /
+ * zero opacity, Gaussians with no tile inside get radii = 0, and the backward returns the band's share of every gradient
+ * and of dL/dtau -- the shares of disjoint bands covering the frame add up to the whole-frame result (every gradient is a
+ * sum over pixels).  The setting is kept in the image workspace (stream-ordered) until changed; [0, rows) restores the
+ * whole frame.  In a batched workspace set it on each view's block. */
+int gsaj_set_tile_band(int W, int H, void *image_ws, int tile_row_begin, int tile_row_end, void *stream);
 /* gsaj_forward_preprocess with the arena capacity check armed (capacity = 0: unchecked). */
 int gsaj_forward_preprocess_cap(int P, int D, int M, int W, int H,
                                 const float *means3D, const float *shs, const float *colors_precomp,
