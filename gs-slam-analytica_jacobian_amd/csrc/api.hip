@@ -226,6 +226,7 @@ int gsaj_set_tile_band(int W, int H, void *image_ws, int tile_row_begin, int til
   }
   const uint32_t band = whole ? 0u : ((uint32_t)tile_row_begin | ((uint32_t)tile_row_end << 16));
   GSAJ_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(im.sticky + 1), (int)band, 1, (hipStream_t)stream));
+  GSAJ_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(im.sticky + 2), (int)~band, 1, (hipStream_t)stream));
   return GSAJ_OK;
 }
 

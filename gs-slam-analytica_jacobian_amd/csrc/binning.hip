@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void k_ranges_records(int R, int gx, int gy, c
   records[(size_t)k * REC_F4 + 0] = make_float4(xy.x, xy.y, depth, __uint_as_float(id));
   records[(size_t)k * REC_F4 + 1] = co;
   int x0, y0, x1, y1;
-  tile_rect(xy.x, xy.y, radii[id], gx, gy, sticky[1], x0, y0, x1, y1);
+  tile_rect(xy.x, xy.y, radii[id], gx, gy, gsaj_tile_band(sticky), x0, y0, x1, y1);
   const int ty = (int)tile / gx, tx = (int)tile - ty * gx;
   const uint32_t u = g.point_offsets[id] - g.tiles_touched[id] + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
   records[(size_t)k * REC_F4 + 2] = make_float4(features[3 * (size_t)id], features[3 * (size_t)id + 1],

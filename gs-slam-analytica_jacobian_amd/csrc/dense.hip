@@ -17,6 +17,11 @@
 #include "gsaj_common.h"
 #include "wave_reduce.h"
 
+struct DensePixelMap {  // where pixel (col, row) sits in the coordinates of means2D / covs2D
+  int normalised;       // 0: (col, row) themselves (compare.py:1226-1229)
+  double fx, fy, cx, cy;  // 1: ((col - cx) / fx, (row - cy) / fy)   (script.py:873-877)
+};
+
 #define DCHUNK 128  // Gaussians staged per LDS chunk
 #define DPAR 12     // floats per staged Gaussian: mu(2) inv(4) colour(3) depth opacity pad
 
@@ -49,14 +54,20 @@ __global__ __launch_bounds__(256) void k_dense_bwd(int N, int W, int H, const fl
                                                    const float *__restrict__ covs2D, const float *__restrict__ colors,
                                                    const float *__restrict__ depths, const float *__restrict__ opac,
                                                    const float *__restrict__ seed_color,
-                                                   const float *__restrict__ seed_depth, float *__restrict__ slab, int naive) {
+                                                   const float *__restrict__ seed_depth, float *__restrict__ slab, int naive,
+                                                   DensePixelMap pm) {
   __shared__ float par[DCHUNK * DPAR];
   __shared__ float acc[DCHUNK * 4 * IGRAD_F];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const size_t HW = (size_t)W * H;
   const size_t pid = (size_t)blockIdx.x * 256 + tid;
   const bool inside = pid < HW;
-  const float u = inside ? (float)(pid % W) : 0.f, v = inside ? (float)(pid / W) : 0.f;
+  float u = inside ? (float)(pid % W) : 0.f, v = inside ? (float)(pid / W) : 0.f;
+  if (pm.normalised && inside) {
+    // the normalised-coordinate variant (Loss_Derivative_script.py:873-877): x_n = (u - cx) / fx in float64, then float32
+    u = (float)(((double)(pid % W) - pm.cx) / pm.fx);
+    v = (float)(((double)(pid / W) - pm.cy) / pm.fy);
+  }
   float gC[3] = {0.f, 0.f, 0.f}, gD = 0.f;
   if (inside) {
     gC[0] = seed_color[3 * pid]; gC[1] = seed_color[3 * pid + 1]; gC[2] = seed_color[3 * pid + 2];
@@ -461,11 +472,19 @@ size_t gsaj_dense_workspace_bytes(int N, int W, int H) {
 int gsaj_dense_backward(int N, int W, int H, const float *means2D, const float *covs2D, const float *colors,
                         const float *depths, const float *opac, const float *seed_color, const float *seed_depth,
                         float *grad_mu, float *grad_Sigma, float *grad_depth, float *grad_color, void *dense_ws,
-                        int flags, void *stream) {
+                        int flags, const double *intrinsics, void *stream) {
   if (N <= 0 || W <= 0 || H <= 0 || !means2D || !covs2D || !colors || !depths || !opac || !seed_color || !seed_depth ||
       !grad_mu || !grad_Sigma || !grad_depth || !grad_color || !dense_ws) {
     gsaj_set_error("gsaj_dense_backward: invalid argument");
     return GSAJ_ERR_INVALID_ARGUMENT;
+  }
+  DensePixelMap pm = {0, 1.0, 1.0, 0.0, 0.0};
+  if (flags & GSAJ_DENSE_NORMALISED_COORDS) {
+    if (!intrinsics || !(intrinsics[0] != 0.0) || !(intrinsics[1] != 0.0)) {
+      gsaj_set_error("gsaj_dense_backward: GSAJ_DENSE_NORMALISED_COORDS needs intrinsics = {fx, fy, cx, cy} with fx, fy != 0");
+      return GSAJ_ERR_INVALID_ARGUMENT;
+    }
+    pm = DensePixelMap{1, intrinsics[0], intrinsics[1], intrinsics[2], intrinsics[3]};
   }
   hipStream_t s = (hipStream_t)stream;
   const int nblk = (int)(((size_t)W * H + 255) / 256);
@@ -473,7 +492,7 @@ int gsaj_dense_backward(int N, int W, int H, const float *means2D, const float *
   {
     GsajProfScope ps(ST_DENSE_BWD, s);
     hipLaunchKernelGGL(k_dense_bwd, dim3(nblk), dim3(256), 0, s, N, W, H, means2D, covs2D, colors, depths, opac, seed_color,
-                       seed_depth, slab, (flags & GSAJ_DENSE_NAIVE_GUARDS) ? 1 : 0);
+                       seed_depth, slab, (flags & GSAJ_DENSE_NAIVE_GUARDS) ? 1 : 0, pm);
   }
   GsajProfScope ps(ST_DENSE_REDUCE, s);
   hipLaunchKernelGGL(k_dense_reduce, dim3((N * 10 + 255) / 256), dim3(256), 0, s, N, nblk, slab, grad_mu, grad_Sigma,

@@ -89,7 +89,7 @@ struct ImageWS {  // reference: ImageState, rasterizer_impl.h:46-53
   uint32_t *tile_count;   // [tiles*TILE_REP]         | zeroed by ONE memset per forward
   uint32_t *tile_cursor;  // [tiles*TILE_REP]        -+
   uint32_t *tile_offset;  // [tiles*TILE_REP + 1] exclusive scan of tile_count (tile-major)
-  uint32_t *sticky;       // [16] never zeroed by a forward: [0] number of aborted async forwards, [1] tile band (tile_rect)
+  uint32_t *sticky;       // [16] never zeroed by a forward: [0] number of aborted async forwards, [1] tile band, [2] its complement (gsaj_tile_band)
   uint32_t *finish_list;  // [tiles] tile indices in the order their forward workgroups finished (counters[6] = how many)
   size_t zero_bytes;      // bytes from counters to the end of tile_cursor
 };
@@ -264,6 +264,12 @@ __device__ __forceinline__ float ndc2pix(float v, int S) { return (float)((((dou
 // A banded frame clips every Gaussian's tile rectangle to rows [begin, end): tiles outside get empty lists, Gaussians
 // with no tile inside get radius 0, and every per-Gaussian sum covers the band's tiles only (tile-band sharding of one
 // frame over ranks, DESIGN.md "Multi-GPU").
+// The band word is honoured only with its complement beside it (sticky[2] == ~sticky[1]): the synchronous entry points do not
+// ask for a zeroed image workspace, and uninitialised memory must not pass for a band.
+__device__ __forceinline__ uint32_t gsaj_tile_band(const uint32_t *__restrict__ sticky) {
+  const uint32_t band = sticky[1];
+  return sticky[2] == ~band ? band : 0u;
+}
 __device__ __forceinline__ void tile_rect(float px, float py, int r, int gx, int gy, uint32_t band, int &x0, int &y0, int &x1,
                                           int &y1) {
   const int ylo = band ? (int)(band & 0xffffu) : 0, yhi = band ? min(gy, (int)(band >> 16)) : gy;

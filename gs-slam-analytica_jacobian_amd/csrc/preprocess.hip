@@ -191,7 +191,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__re
         const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
         const float2 pim = make_float2(ndc2pix(p_proj.x, p.W), ndc2pix(p_proj.y, p.H));
         int x0, y0, x1, y1;
-        tile_rect(pim.x, pim.y, (int)my_radius, p.grid_x, p.grid_y, im.sticky[1], x0, y0, x1, y1);
+        tile_rect(pim.x, pim.y, (int)my_radius, p.grid_x, p.grid_y, gsaj_tile_band(im.sticky), x0, y0, x1, y1);
         const int area = (x1 - x0) * (y1 - y0);
         if (area != 0) {
           if (!p.colors_precomp) {
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scatter_instances(int P, int gx, 
     const float2 xy = g.means2D[idx];  // requested together with the radius, not after it (latency-bound kernel)
     const float dep = g.depths[idx];
     if (r > 0) {
-      tile_rect(xy.x, xy.y, r, gx, gy, im.sticky[1], x0, y0, x1, y1);
+      tile_rect(xy.x, xy.y, r, gx, gy, gsaj_tile_band(im.sticky), x0, y0, x1, y1);
       key = ((uint64_t)__float_as_uint(dep) << 32) | (uint32_t)idx;
     }
   }
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_emit_keys(int P, int gx, int gy, 
     uint32_t off = incl - g.tiles_touched[idx];
     const float2 xy = g.means2D[idx];
     int x0, y0, x1, y1;
-    tile_rect(xy.x, xy.y, r, gx, gy, sticky[1], x0, y0, x1, y1);
+    tile_rect(xy.x, xy.y, r, gx, gy, gsaj_tile_band(sticky), x0, y0, x1, y1);
     const uint32_t dbits = __float_as_uint(g.depths[idx]);
     for (int y = y0; y < y1; y++)
       for (int x = x0; x < x1; x++) {

@@ -47,7 +47,7 @@ SIGNATURES = {
     "gsaj_profile_begin": (c_int, [c_int]),
     "gsaj_profile_end": (c_int, [P, P]),
     "gsaj_dense_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "gsaj_dense_backward": (c_int, [c_int, c_int, c_int] + [P] * 7 + [P] * 4 + [P, c_int, P]),
+    "gsaj_dense_backward": (c_int, [c_int, c_int, c_int] + [P] * 7 + [P] * 4 + [P, c_int, P, P]),
     "gsaj_dense_project_workspace_bytes": (c_size_t, [c_int]),
     "gsaj_dense_project": (c_int, [c_int] * 5 + [P] * 6 + [c_double, c_double] + [P] * 6 + [P, P]),
     "gsaj_dense_render": (c_int, [c_int, c_int, c_int] + [P] * 5 + [P, P, P]),

@@ -15,6 +15,8 @@ grad_mu_I_pixel.npy, grad_Sigma_I_pixel.npy, grad_depth_per_gaussian.npy and dL_
 
 All arithmetic runs in libgsaj_hip.so; torch only holds the device buffers.
 """
+import ctypes
+
 import numpy as np
 import torch
 
@@ -84,10 +86,13 @@ def jacobian_test(means3D, cov3D6, opacities, shs, cam, gt_color, gt_depth, mask
                 dL_dtau=tau, dL_dtau_parts=parts, order=pr["order"], rendered_color=img, rendered_depth=dep, projected=pr)
 
 
-def compute_gradients_2D(means_2D, covs_2D, colors, depths, alphas, grad_color, grad_depth, device="cuda:0", naive_guards=False):
+def compute_gradients_2D(means_2D, covs_2D, colors, depths, alphas, grad_color, grad_depth, device="cuda:0", naive_guards=False,
+                         normalised_intrinsics=None):
     """Depth-sorted projected Gaussians + per-pixel seeds -> (grad_mu_I [N,2], grad_Sigma_I [N,2,2],
     grad_depth_per_gaussian [N], grad_color_per_gaussian [N,3]), fp32, rows in sorted order.
-    naive_guards=True: edge semantics of the naive per-pixel loop (GSAJ_DENSE_NAIVE_GUARDS)."""
+    naive_guards=True: edge semantics of the naive per-pixel loop (GSAJ_DENSE_NAIVE_GUARDS).
+    normalised_intrinsics=(fx, fy, cx, cy): the variant of Loss_Derivative_script.py:820-979 -- means / covariances in
+    normalised image coordinates, pixels at ((col - cx) / fx, (row - cy) / fy) (GSAJ_DENSE_NORMALISED_COORDS)."""
     lib = _lib.load()
     dev = torch.device(device)
     m2, c2 = _dev(means_2D, _F, dev), _dev(covs_2D, _F, dev)
@@ -101,10 +106,15 @@ def compute_gradients_2D(means_2D, covs_2D, colors, depths, alphas, grad_color, 
     g_z = torch.empty((N,), dtype=_F, device=dev)
     g_c = torch.empty((N, 3), dtype=_F, device=dev)
     ws = torch.empty(lib.gsaj_dense_workspace_bytes(N, W, H), dtype=torch.uint8, device=dev)
+    flags, intr = (1 if naive_guards else 0), None
+    if normalised_intrinsics is not None:
+        intr = (ctypes.c_double * 4)(*[float(x) for x in normalised_intrinsics])
+        flags |= 2
     with torch.cuda.device(dev):
         _lib.check(lib.gsaj_dense_backward(N, W, H, m2.data_ptr(), c2.data_ptr(), col.data_ptr(), dep.data_ptr(),
                                            op.data_ptr(), gc.data_ptr(), gd.data_ptr(), g_mu.data_ptr(), g_S.data_ptr(),
-                                           g_z.data_ptr(), g_c.data_ptr(), ws.data_ptr(), 1 if naive_guards else 0, _stream(dev)),
+                                           g_z.data_ptr(), g_c.data_ptr(), ws.data_ptr(), flags,
+                                           None if intr is None else ctypes.cast(intr, ctypes.c_void_p), _stream(dev)),
                    "gsaj_dense_backward")
     return g_mu, g_S, g_z, g_c
 

@@ -140,7 +140,8 @@ int gsaj_forward_aborted_count(int W, int H, const void *image_ws, void *stream,
  * zero opacity, Gaussians with no tile inside get radii = 0, and the backward returns the band's share of every gradient
  * and of dL/dtau -- the shares of disjoint bands covering the frame add up to the whole-frame result (every gradient is a
  * sum over pixels).  The setting is kept in the image workspace (stream-ordered) until changed; [0, rows) restores the
- * whole frame.  In a batched workspace set it on each view's block. */
+ * whole frame.  In a batched workspace set it on each view's block.  A workspace this call never touched renders the whole
+ * frame whatever its bytes are (the band word is stored with its complement and ignored unless both agree). */
 int gsaj_set_tile_band(int W, int H, void *image_ws, int tile_row_begin, int tile_row_end, void *stream);
 /* gsaj_forward_preprocess with the arena capacity check armed (capacity = 0: unchecked). */
 int gsaj_forward_preprocess_cap(int P, int D, int M, int W, int H,
@@ -321,10 +322,15 @@ size_t gsaj_dense_workspace_bytes(int N, int W, int H);
  * alpha_i >= 0.999 the suffix term is dropped rather than divided by 1.0, and an entry with abs(alpha_i) < 1e-8 adds nothing to
  * grad_mu / grad_Sigma. */
 #define GSAJ_DENSE_NAIVE_GUARDS 1
+/* GSAJ_DENSE_NORMALISED_COORDS: the variant of Loss_Derivative_script.py:820-979 -- means2D / covs2D are in NORMALISED image
+ * coordinates and pixel (col, row) sits at ((col - cx) / fx, (row - cy) / fy) (float64 arithmetic rounded to float32 as in
+ * :873-877, where the reference reads the module globals cx, fx, cy, fy); `intrinsics` = host {fx, fy, cx, cy}, read only
+ * with this flag (NULL otherwise).  Same arithmetic; the gradients come out in normalised units. */
+#define GSAJ_DENSE_NORMALISED_COORDS 2
 int gsaj_dense_backward(int N, int W, int H, const float *means2D, const float *covs2D, const float *colors,
                         const float *depths, const float *opac, const float *seed_color, const float *seed_depth,
                         float *grad_mu, float *grad_Sigma, float *grad_depth, float *grad_color,
-                        void *dense_ws, int flags, void *stream);
+                        void *dense_ws, int flags, const double *intrinsics /*host [4] or NULL*/, void *stream);
 /* Front end of the NumPy path (GetImagePlaneMeanAndCovs + compute_cov2d + ndc2Pix + compute_colors_from_sh +
  * OrderGaussiansByDepth, compare.py:854-971, 772-852, 535-588, 764-769), fp64 arithmetic on the fp32 inputs like the
  * reference's Python floats, Appendix A.4 semantics: no z <= 0.2 cull, no tile test, colours clamped below at 0 only, one

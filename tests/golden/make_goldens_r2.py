@@ -16,6 +16,11 @@ the reference files are parsed, only their top-level `def`s are exec'd, fixtures
   naive_edge_N5_12x9.npz        Loss_Derivative_wrt_mu_and_cov.compute_gradients_2D (the O(HWN^2) loop) on a scene that
                                 exercises its two edge branches: alpha >= 0.999 (suffix term dropped, wrt.py:75-82) and
                                 abs(alpha) < 1e-8 (entry skipped, wrt.py:93-94).
+  dense_normalised_N{15,64}_64x48.npz
+                                the NORMALISED-coordinate variant of the chunked backward, Loss_Derivative_script.py:820-979
+                                (pixel grid (u - cx) / fx, (v - cy) / fy from the module globals cx, fx, cy, fy -- injected here;
+                                no mask; returns grad_mu, grad_Sigma only), on the projected Gaussians of dense_N{15,64}_64x48.npz
+                                converted to normalised coordinates.
 """
 import os
 import sys
@@ -99,6 +104,25 @@ def naive_edge_fixture(ref_wrt):
                 grad_mu=np.array(g_mu), grad_Sigma=np.array(g_S))
 
 
+def dense_normalised_fixture(name, seed):
+    g = np.load(os.path.join(HERE, name + ".npz"))
+    fx, fy, cx, cy = (float(g[k]) for k in ("fx", "fy", "cx", "cy"))
+    H, W, N = int(g["H"]), int(g["W"]), int(g["N"])
+    ref = mg.load_defs(os.path.join(REF, "Loss_Derivative_script.py"), extra=dict(fx=fx, fy=fy, cx=cx, cy=cy))
+    o = g["order"]
+    mean_n = (g["mean_2D"] - np.array([cx, cy])) / np.array([fx, fy])
+    cov_n = g["cov_2D"] / np.array([[fx * fx, fx * fy], [fx * fy, fy * fy]])
+    gl = [dict(mean_2D=mean_n[i], cov_2D=cov_n[i], color=g["color"][i], depth=g["depth"][i], alpha=g["opacities"][o[i], 0])
+          for i in range(N)]
+    rng = np.random.default_rng(seed)
+    rc, rd = rng.normal(size=(H, W, 3)), rng.normal(size=(H, W))
+    g_mu, g_S = mg.quiet(ref["compute_gradients_2D_vectorized_chunked"], gl, rc, rd, np.zeros((H, W, 3)), np.zeros((H, W)), (H, W),
+                         chunk_size=500)
+    return dict(H=H, W=W, N=N, fx=fx, fy=fy, cx=cx, cy=cy, mean_2D=mean_n, cov_2D=cov_n, color=np.asarray(g["color"]),
+                depth=np.asarray(g["depth"]), alpha=np.array([d["alpha"] for d in gl]), seed_color=np.sign(rc).astype(np.int8),
+                seed_depth=np.sign(rd).astype(np.int8), grad_mu=np.asarray(g_mu), grad_Sigma=np.asarray(g_S))
+
+
 def main():
     ref = mg.load_defs(os.path.join(REF, "Loss_Derivative_script_compare.py"))
     ref_wrt = mg.load_defs(os.path.join(REF, "Loss_Derivative_wrt_mu_and_cov.py"))
@@ -106,7 +130,10 @@ def main():
     np.savez_compressed(os.path.join(HERE, "jacobian_chain_ortho.npz"), **jacobian_chain_fixture(ref, True, 321))
     np.savez_compressed(os.path.join(HERE, "jacobian_chain_similarity.npz"), **jacobian_chain_fixture(ref, False, 322))
     np.savez_compressed(os.path.join(HERE, "naive_edge_N5_12x9.npz"), **naive_edge_fixture(ref_wrt))
-    for n in ("dense_render_N15_640x480", "jacobian_chain_ortho", "jacobian_chain_similarity", "naive_edge_N5_12x9"):
+    np.savez_compressed(os.path.join(HERE, "dense_normalised_N15_64x48.npz"), **dense_normalised_fixture("dense_N15_64x48", 15))
+    np.savez_compressed(os.path.join(HERE, "dense_normalised_N64_64x48.npz"), **dense_normalised_fixture("dense_N64_64x48", 64))
+    for n in ("dense_render_N15_640x480", "jacobian_chain_ortho", "jacobian_chain_similarity", "naive_edge_N5_12x9",
+              "dense_normalised_N15_64x48", "dense_normalised_N64_64x48"):
         print(n, os.path.getsize(os.path.join(HERE, n + ".npz")), "bytes")
 
 

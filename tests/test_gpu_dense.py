@@ -110,6 +110,28 @@ def test_naive_loop_goldens_on_the_device(golden_dir, name, naive):
         assert np.all(mu.cpu().numpy()[inv][3] == 0)  # the 1e-9-opacity entry is skipped entirely, as in the loop
 
 
+@pytest.mark.parametrize("name", ["dense_normalised_N15_64x48.npz", "dense_normalised_N64_64x48.npz"])
+def test_normalised_coordinate_variant_on_the_device(golden_dir, name):
+    """a3, second producer: Loss_Derivative_script.py:820-979 (normalised image coordinates; GSAJ_DENSE_NORMALISED_COORDS) against
+    the fixtures that function produced, and against the oracle on the same inputs."""
+    from gsaj import dense
+    from oracle import dense_oracle as dor
+
+    g = np.load(os.path.join(golden_dir, name))
+    intr = (float(g["fx"]), float(g["fy"]), float(g["cx"]), float(g["cy"]))
+    args = (g["mean_2D"], g["cov_2D"], g["color"], g["depth"], g["alpha"], g["seed_color"].astype(np.float32),
+            g["seed_depth"].astype(np.float32))
+    mu, S, z, c = (x.cpu().numpy() for x in dense.compute_gradients_2D(*args, normalised_intrinsics=intr))
+    m_mu, m_S = np.abs(g["grad_mu"]).max(), np.abs(g["grad_Sigma"]).max()
+    assert np.abs(mu - g["grad_mu"]).max() < 2e-5 * m_mu
+    assert np.abs(S - g["grad_Sigma"]).max() < 2e-5 * m_S
+    o_mu, o_S, o_z, o_c = dor.dense_backward(*args, normalised_intrinsics=intr)
+    for got, want in ((mu, o_mu), (S, o_S), (z, o_z), (c, o_c)):
+        assert np.abs(got - want).max() < 2e-5 * np.abs(want).max()
+    with pytest.raises(Exception, match="NORMALISED_COORDS"):
+        dense.compute_gradients_2D(*args, normalised_intrinsics=(0.0, 1.0, 0.0, 0.0))
+
+
 def test_dense_render_reference_golden(golden_dir):
     """a10: rendered_Image_from_Projected_Gaussians_vectorized (compare.py:973-1018) -- the clipped image the reference hands to
     plt.imshow, recorded by tests/golden/make_goldens_r2.py (every 4th row / column + row and column sums of the full image)."""

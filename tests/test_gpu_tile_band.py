@@ -177,6 +177,26 @@ def test_band_is_kept_until_changed_and_whole_frame_restores_bitwise():
     assert torch.equal(g["tau_sum"], gw["tau_sum"]) and torch.equal(g["mean3D"], gw["mean3D"])
 
 
+def test_uninitialised_image_workspace_is_not_mistaken_for_a_band():
+    """The synchronous entry points do not ask for a zeroed image workspace (the drop-in binding hands over torch.empty
+    memory): whatever bytes it holds, the whole frame is rendered."""
+    import torch
+    from gsaj.rasterizer import FrameContext
+
+    cam, sc, deg = hp.make("p2000_160x120")
+    dLc, dLd = hp.seeds(cam, seed=3)
+    whole, _ = _frame(cam, sc, deg, None, dLc, dLd)
+    dev, t, M, kw, a = _tensors(cam, sc)
+    for fill in (0xFF, 0x01, None):
+        fc = FrameContext(sc["means3D"].shape[0], cam["W"], cam["H"], M, dev)
+        if fill is None:
+            fc.img.random_(0, 256)
+        else:
+            fc.img.fill_(fill)
+        fc.forward(a["bg"], a["means"], a["opac"], a["view"], a["proj"], a["campos"], cam["tanfovx"], cam["tanfovy"], sh_degree=deg, **kw)
+        assert torch.equal(fc.color, whole.color) and torch.equal(fc.radii, whole.radii)
+
+
 def test_empty_band_renders_nothing_and_bad_bands_are_refused():
     import torch
     cam, sc, deg = hp.make("p2000_160x120")

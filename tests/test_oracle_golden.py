@@ -171,6 +171,23 @@ def test_naive_loop_edge_branches_golden(golden_dir):
     assert np.all(mu[inv][3] == 0) and np.all(g["grad_mu"][3] == 0)  # the 1e-9-opacity entry is skipped entirely
 
 
+@pytest.mark.parametrize("name", ["dense_normalised_N15_64x48.npz", "dense_normalised_N64_64x48.npz"])
+def test_normalised_coordinate_variant_golden(golden_dir, name):
+    """The normalised-coordinate variant of the chunked backward (Loss_Derivative_script.py:820-979: pixel grid (u - cx) / fx,
+    (v - cy) / fy from module globals, no mask) -- fixtures produced by that function itself (make_goldens_r2.py)."""
+    g = _load(golden_dir, name)
+    intr = (float(g["fx"]), float(g["fy"]), float(g["cx"]), float(g["cy"]))
+    mu, S = dor.dense_backward(g["mean_2D"], g["cov_2D"], g["color"], g["depth"], g["alpha"], g["seed_color"].astype(np.float32),
+                               g["seed_depth"].astype(np.float32), normalised_intrinsics=intr)[:2]
+    m_mu, m_S = np.abs(g["grad_mu"]).max(), np.abs(g["grad_Sigma"]).max()
+    e_mu, e_S = np.abs(mu - g["grad_mu"]).max() / m_mu, np.abs(S - g["grad_Sigma"]).max() / m_S
+    assert e_mu < 2e-5 and e_S < 2e-5, (e_mu, e_S)  # both sides sum ~3000 fp32 terms per Gaussian in different orders
+    # the pixel-coordinate semantics on the same arrays are a different function altogether
+    mu_px = dor.dense_backward(g["mean_2D"], g["cov_2D"], g["color"], g["depth"], g["alpha"], g["seed_color"].astype(np.float32),
+                               g["seed_depth"].astype(np.float32))[0]
+    assert np.abs(mu_px - g["grad_mu"]).max() > 1e-2 * m_mu
+
+
 def test_dense_render_golden(golden_dir):
     """rendered_Image_from_Projected_Gaussians_vectorized (compare.py:973-1018): the image the reference hands to imshow."""
     g = _load(golden_dir, "dense_N15_640x480.npz")
