@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
   __syncthreads();
   const uint32_t bmax = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
 
-  float accC0 = 0.f, accC1 = 0.f, accC2 = 0.f, accD = 0.f;  // accum_rec, accum_rec_depth
+  float accS = 0.f;  // (accum_rec, accum_rec_depth) . (dL/dC, dL/dD) of this pixel: the only form the recurrences are needed in
 
   // phase-2 lane roles
   const int p2_slot = lane & (SLOTS - 1), p2_row = lane >> 3;
@@ -224,26 +224,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
           const float dx = r0.x - pxf, dy = r0.y - pyf;
           // the forward's own expression (gsaj_common.h): both passes decide power <= 0 / alpha >= 1/255 on identical bits
           const float p2 = gsaj_power2(dx, dy, r1.x, r1.y, r1.z);
-          const float G0 = __builtin_amdgcn_exp2f(p2);
-          const float alpha0 = fminf(0.99f, r1.w * G0);
+          const float oG = r1.w * __builtin_amdgcn_exp2f(p2);  // opacity x G
+          const float alpha0 = fminf(0.99f, oG);
           const bool valid = idx < last && p2 <= 0.0f && alpha0 >= (1.0f / 255.0f);
           if (__builtin_amdgcn_ballot_w64(valid) != 0ull) {
-            // a lane that skips this entry runs the same arithmetic with alpha = G = 0: T and accum_rec
-            // come out unchanged and (w, u) = 0
+            // a lane that skips this entry runs the same arithmetic with alpha = 0: T and the recurrence come out unchanged
+            // and (w, u) = 0
             const float alpha = valid ? alpha0 : 0.f;
-            const float G = valid ? G0 : 0.f;
             const float inv1ma = __builtin_amdgcn_rcpf(1.f - alpha);
             T = T * inv1ma;  // T <- T / (1 - alpha)
-            const float d0 = r2.x - accC0, d1 = r2.y - accC1, d2 = r2.z - accC2, d3 = r0.z - accD;
-            float dL_dalpha = d0 * gC0 + d1 * gC1 + d2 * gC2 + d3 * gD;
-            dL_dalpha = dL_dalpha * T - Tf_bg * inv1ma;
-            // accum_rec for the next (nearer) entry: alpha c + (1 - alpha) accum_rec (backward.cu:799,811), written
-            // as accum_rec + alpha (c - accum_rec); applied here instead of lazily at the top of the next iteration
-            accC0 += alpha * d0;
-            accC1 += alpha * d1;
-            accC2 += alpha * d2;
-            accD += alpha * d3;
-            wu[nslot * WU_STRIDE + lane] = make_float2((r1.w * dL_dalpha) * G, alpha * T);
+            // dL/dalpha needs accum_rec only through its product with this pixel's seeds, sum_ch (c_ch - accum_rec_ch) g_ch
+            // (backward.cu:799-823, colour and depth alike): the four recurrences accum_rec <- alpha c + (1 - alpha) accum_rec
+            // collapse into ONE for the scalar s = accum_rec . g, s <- s + alpha (c . g - s) -- 6 VALU operations per entry
+            // instead of 12, same value up to fp32 rounding (the dot product is linear in accum_rec)
+            const float cg = r2.x * gC0 + r2.y * gC1 + r2.z * gC2 + r0.z * gD;
+            const float dd = cg - accS;
+            const float dL_dalpha = dd * T - Tf_bg * inv1ma;
+            accS += alpha * dd;
+            // w = dL/dG * G = (o dL/dalpha) G (backward.cu:826-829; G, not the clamped alpha): o G is at hand from the alpha test
+            wu[nslot * WU_STRIDE + lane] = make_float2(valid ? dL_dalpha * oG : 0.f, alpha * T);
             slot_entry = (lane == nslot) ? j : slot_entry;
             nslot++;
             if (nslot == SLOTS) flush();
