@@ -194,17 +194,19 @@ int gsaj_forward_num_rendered(int W, int H, const void *image_ws, void *stream, 
   return GSAJ_OK;
 }
 
-int gsaj_forward_aborted_count(int W, int H, const void *image_ws, void *stream, int *count) {
+int gsaj_forward_aborted_count(int W, int H, void *image_ws, void *stream, int *count) {
   if (W <= 0 || H <= 0 || !image_ws || !count) {
     gsaj_set_error("gsaj_forward_aborted_count: invalid argument");
     return GSAJ_ERR_INVALID_ARGUMENT;
   }
   ImageWS im;
-  image_carve(align_base(const_cast<void *>(image_ws)), W, H, &im);
+  image_carve(align_base(image_ws), W, H, &im);
   uint32_t host = 0;
   GSAJ_HIP_CHECK(hipMemcpyAsync(&host, im.sticky, sizeof(host), hipMemcpyDeviceToHost, (hipStream_t)stream));
   GSAJ_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
   *count = (int)host;
+  // read and clear: the next call reports the aborts since this one (a caller that re-sized its arena starts from zero)
+  if (host) GSAJ_HIP_CHECK(hipMemsetAsync(im.sticky, 0, sizeof(uint32_t), (hipStream_t)stream));
   return GSAJ_OK;
 }
 

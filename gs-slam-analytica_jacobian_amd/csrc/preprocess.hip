@@ -649,7 +649,9 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_mark_visible(int P, const float *
   present[idx] = pv.z > 0.2f;
 }
 
-// zero the frame counters + tile histogram / cursors of every view of a batched launch (one launch instead of K memsets)
+// zero the frame counters + tile histogram / cursors of every view (one launch for K views).  A kernel also for K = 1, not
+// hipMemsetAsync: a forward captured into a hipGraph must replay correctly, and on ROCm 7.2 a captured memset node stopped
+// taking effect from the second replay on whenever the host had synchronised in between (tests/test_gpu_device_tracker.py)
 __global__ __launch_bounds__(256) void k_zero_frame_state(uint32_t *__restrict__ counters, size_t words, size_t view_stride) {
   uint32_t *c = gsaj_shift(counters, blockIdx.y * view_stride);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) c[i] = 0u;
@@ -659,9 +661,7 @@ int launch_preprocess(const FwdParams &p, int *radii, int *n_touched, const Geom
                       hipStream_t s) {
   const int nblk = (p.P + PRE_BLOCK - 1) / PRE_BLOCK;
   const int views = p.views > 0 ? p.views : 1;
-  if (views == 1) {
-    GSAJ_HIP_CHECK(hipMemsetAsync(im.counters, 0, im.zero_bytes, s));  // the only memset of a forward
-  } else {
+  {
     const size_t words = im.zero_bytes / sizeof(uint32_t);
     hipLaunchKernelGGL(k_zero_frame_state, dim3((unsigned)((words + 1023) / 1024), views), dim3(256), 0, s, im.counters, words,
                        vs.image);

@@ -71,14 +71,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
   float2 *wu = wu_all + wave * SLOTS * WU_STRIDE;
   float4 *seed = seed_all + wave * 64;
   // longest-running forward tiles first (clamped: a stale list must not become an out-of-range tile)
-  const int tile = (int)min(finish_list[gridDim.x - 1 - blockIdx.x], gridDim.x - 1);
+  const int tile = __builtin_amdgcn_readfirstlane((int)min(finish_list[gridDim.x - 1 - blockIdx.x], gridDim.x - 1));
   const int ty = tile / gx, tx = tile - ty * gx;
   const int px = tx * TILE + (wave & 1) * 8 + (lane & 7);
   const int py = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
   const bool inside = px < W && py < H;
   const float pxf = (float)px, pyf = (float)py;
   const float qx0 = (float)(tx * TILE + (wave & 1) * 8), qy0 = (float)(ty * TILE + (wave >> 1) * 8);
-  const uint2 range = ranges[tile];
+  const uint2 range_v = ranges[tile];  // workgroup-uniform: into scalar registers, with everything derived from it (hi, lo, n, first_idx)
+  const uint2 range = make_uint2((uint32_t)__builtin_amdgcn_readfirstlane((int)range_v.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)range_v.y));
   const size_t pid = (size_t)py * W + px, HW = (size_t)H * W;
 
   const float T_final = inside ? final_T[pid] : 0.f;
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
   const int p2_slot = lane & (SLOTS - 1), p2_row = lane >> 3;
   const float p2_py = qy0 + (float)p2_row;
 
-  uint32_t hi = range.x + bmax;  // exclusive sorted position
+  uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(range.x + bmax));  // exclusive sorted position (workgroup-uniform: kept in scalar registers)
   // entries [hi, range.y) were never reached by any pixel of the tile: their partials are zero.  Only a one-byte
   // flag says so (opaque scenes leave most of a long list unreached: 48-byte zero rows would be most of the traffic)
   const bool rec16 = counters[7] != 0u;  // fp16-storage records (gsaj_common.h)
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     }
     __syncthreads();
 
-    const uint32_t first_idx = lo - range.x;  // list index (0-based) of rec[0]
+    const uint32_t first_idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lo - range.x));  // list index (0-based) of rec[0]; workgroup-uniform -> scalar
     if (wmax > first_idx) {
       // lane l tests entry l against this wave's quadrant (and its furthest last contributor)
       bool rel = false;
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
       }
       unsigned long long todo = __builtin_amdgcn_ballot_w64(rel);
       int nslot = 0;      // accepted entries waiting in wu[] (wave-uniform)
-      int slot_entry = 0;  // lane s (< SLOTS): round-local index j of the entry in slot s
+      unsigned long long slot_pack = 0ull;  // byte s: round-local index j of the entry in slot s (wave-uniform: scalar registers)
 
       // ---- phase 2: moments of the queued (w, u) rows -> per-entry totals in this wave's acc slots ----
       auto flush = [&]() {
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         // three running sums of w (1, x', x'^2) give every second moment of the row about the Gaussian's mean:
         // dx = ax - x' (ax = mean x - centre column), dy constant along the row.  Slots beyond nslot hold stale rows;
         // slots never mix, and only live ones are stored.
-        const int j = __shfl(slot_entry, p2_slot);
+        const int j = (int)((slot_pack >> (8 * p2_slot)) & 0xffull);
         const float4 e0 = rec[j * REC_F4 + 0];
         float4 e1 = rec[j * REC_F4 + 1];
         e1.x *= -2.0f / GSAJ_LOG2E; e1.y *= -1.0f / GSAJ_LOG2E; e1.z *= -2.0f / GSAJ_LOG2E;  // pre-scaled conic -> (a, b, c)
@@ -202,6 +203,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
           if ((r & 1) == 0) a[(8 + (r >> 1)) * ACC_STRIDE] = x2;
         }
         nslot = 0;
+        slot_pack = 0ull;
       };
 
       // ---- phase 1: back-to-front walk over the entries this quadrant can see ----
@@ -225,12 +227,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
           // the forward's own expression (gsaj_common.h): both passes decide power <= 0 / alpha >= 1/255 on identical bits
           const float p2 = gsaj_power2(dx, dy, r1.x, r1.y, r1.z);
           const float oG = r1.w * __builtin_amdgcn_exp2f(p2);  // opacity x G
-          const float alpha0 = fminf(0.99f, oG);
-          const bool valid = idx < last && p2 <= 0.0f && alpha0 >= (1.0f / 255.0f);
+          // alpha = min(0.99, o G) >= 1/255  <=>  o G >= 1/255: the clamp is applied after the mask (one select fewer); the
+          // decision is the forward's bit for bit
+          const bool valid = idx < last && p2 <= 0.0f && oG >= (1.0f / 255.0f);
           if (__builtin_amdgcn_ballot_w64(valid) != 0ull) {
             // a lane that skips this entry runs the same arithmetic with alpha = 0: T and the recurrence come out unchanged
             // and (w, u) = 0
-            const float alpha = valid ? alpha0 : 0.f;
+            const float oGm = valid ? oG : 0.f;
+            float alpha;  // min(0.99, o G); written as the instruction because fminf() on a selected value costs a second one
+                          // (the compiler quiets a possible signalling NaN first: v_max_f32 x, x)
+            asm("v_min_f32 %0, 0x3f7d70a4, %1" : "=v"(alpha) : "v"(oGm));
             const float inv1ma = __builtin_amdgcn_rcpf(1.f - alpha);
             T = T * inv1ma;  // T <- T / (1 - alpha)
             // dL/dalpha needs accum_rec only through its product with this pixel's seeds, sum_ch (c_ch - accum_rec_ch) g_ch
@@ -242,8 +248,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
             const float dL_dalpha = dd * T - Tf_bg * inv1ma;
             accS += alpha * dd;
             // w = dL/dG * G = (o dL/dalpha) G (backward.cu:826-829; G, not the clamped alpha): o G is at hand from the alpha test
-            wu[nslot * WU_STRIDE + lane] = make_float2(valid ? dL_dalpha * oG : 0.f, alpha * T);
-            slot_entry = (lane == nslot) ? j : slot_entry;
+            wu[nslot * WU_STRIDE + lane] = make_float2(dL_dalpha * oGm, alpha * T);
+            slot_pack |= (unsigned long long)j << (8 * nslot);
             nslot++;
             if (nslot == SLOTS) flush();
           }

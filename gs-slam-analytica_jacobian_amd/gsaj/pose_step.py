@@ -22,10 +22,18 @@ class PoseTracker:
             raise _lib.GsajError("PoseTracker needs a HIP device (there is no CPU path)")
         n = self.lib.gsaj_pose_state_floats()
         self.state = torch.zeros(n, dtype=torch.float32, device=self.dev)
-        self.state[0:16] = torch.as_tensor(w2c, dtype=torch.float32).reshape(16).to(self.dev)
         self.projection = torch.as_tensor(projection_matrix, dtype=torch.float32).reshape(4, 4).contiguous().to(self.dev)
         self.lr = (float(lr_rot), float(lr_trans), float(lr_exposure_a), float(lr_exposure_b))
         self.betas, self.eps, self.thr = (float(betas[0]), float(betas[1])), float(eps), float(converged_threshold)
+        self.reset(w2c)
+
+    def reset(self, w2c, exposure=(0.0, 0.0)):
+        """A new frame: pose, zero Adam moments and step count -- IN PLACE, so that views of the state handed out earlier
+        (and hipGraphs captured over them, gsaj.tracking) stay valid."""
+        self.state.zero_()
+        self.state[0:16] = torch.as_tensor(w2c, dtype=torch.float32).reshape(16).to(self.dev)
+        self.state[33] = float(exposure[0])
+        self.state[34] = float(exposure[1])
         # matrices for the first render
         w = self.state[0:16].view(4, 4)
         self.state[35:51] = w.t().reshape(16)

@@ -305,14 +305,16 @@ class FrameContext:
                                        dtype=torch.uint8)
 
     def status(self):
-        """Blocking: (num_rendered, longest tile list) of the last forward; raises if it was aborted."""
+        """Blocking: (num_rendered, longest tile list) of the last forward; raises if it, or any asynchronous forward since the
+        previous status(), was aborted on the device.  The abort counter is read AND cleared first, so that a caller which
+        re-sizes after the exception starts from a clean slate."""
+        n = ctypes.c_int(0)
+        _lib.check(self.lib.gsaj_forward_aborted_count(self.W, self.H, self.img.data_ptr(), _stream(self.dev),
+                                                       ctypes.byref(n)), "gsaj_forward_aborted_count")
         R, mt = ctypes.c_int(0), ctypes.c_int(0)
         _lib.check(self.lib.gsaj_forward_num_rendered(self.W, self.H, self.img.data_ptr(), _stream(self.dev),
                                                       ctypes.byref(R), ctypes.byref(mt)), "gsaj_forward_num_rendered")
         self.true_R = R.value
-        n = ctypes.c_int(0)
-        _lib.check(self.lib.gsaj_forward_aborted_count(self.W, self.H, self.img.data_ptr(), _stream(self.dev),
-                                                       ctypes.byref(n)), "gsaj_forward_aborted_count")
         if n.value:
             raise _lib.GsajError("%d asynchronous forward(s) were aborted on the device (binning arena too small or a tile list "
                                  "longer than tile_list_capacity=%d); run forward(sync=True) to re-size" % (n.value, self.tile_list_capacity))

@@ -7,7 +7,7 @@ band of tile rows (gsaj_set_tile_band: the tile rectangles of cuda_rasterizer/au
 the band's share of dL/dtau, and the shares add up to the whole-frame value.  Per iteration and rank:
 
     forward(band) -> loss seeds -> backward(pose_only)          no collective inside the data path
-    all-reduce(sum) of 11 floats: dL/dtau (6), dL/da, dL/db, loss, L_rgb, L_depth     RCCL ("nccl") / gloo in CPU tests
+    all-reduce(sum) of 11 floats: dL/dtau (6), loss, L_rgb, L_depth, dL/da, dL/db     RCCL ("nccl") / gloo in CPU tests
     pose Adam step + update_pose on every rank                   same input, same arithmetic -> the replicas stay identical
 
 The tracking loss needs no masking for this: its colour term is weighted by the rendered opacity and its depth term is
@@ -20,7 +20,8 @@ import torch
 import torch.distributed as dist
 
 TILE = 16
-REDUCED_FLOATS = 11  # dL/dtau (6) | dL/da, dL/db | loss, L_rgb, L_depth
+REDUCED_FLOATS = 11  # dL/dtau (6) | loss, L_rgb, L_depth, dL/da, dL/db (= the out_scalars[5] of gsaj_loss_seeds, in its order)
+TAU, LOSS_TERMS, EXPOSURE_GRADS = slice(0, 6), slice(6, 9), slice(9, 11)
 
 
 def tile_rows(H):
@@ -83,13 +84,14 @@ def row_work(n_contrib, H=None):
 
 
 def pack_pose_terms(dL_dtau_sum, loss_scalars=None, out=None):
-    """-> the [11] tensor one all-reduce ships: dL/dtau | dL/da, dL/db | loss, L_rgb, L_depth.
-    loss_scalars: out_scalars[5] of gsaj_loss_seeds = {loss, L_rgb, L_depth, dL/da, dL/db} (None: zeros)."""
+    """-> the [11] tensor one all-reduce ships: dL/dtau | loss, L_rgb, L_depth, dL/da, dL/db.
+    loss_scalars: out_scalars[5] of gsaj_loss_seeds = {loss, L_rgb, L_depth, dL/da, dL/db} (None: zeros).  The layout is the two
+    kernels' own output layouts back to back, so a caller can also hand them views of ONE buffer and skip this copy
+    (gsaj.tracking.DeviceTracker does)."""
     out = torch.zeros(REDUCED_FLOATS, dtype=torch.float32, device=dL_dtau_sum.device) if out is None else out
     out[0:6] = dL_dtau_sum
     if loss_scalars is not None:
-        out[6:8] = loss_scalars[3:5]
-        out[8:11] = loss_scalars[0:3]
+        out[6:11] = loss_scalars[0:5]
     else:
         out[6:].zero_()
     return out
@@ -97,7 +99,7 @@ def pack_pose_terms(dL_dtau_sum, loss_scalars=None, out=None):
 
 def allreduce_pose_terms(packed, group=None, async_op=False):
     """Sum the packed band shares over the ranks in place.  Afterwards every rank holds the whole-frame dL/dtau =
-    packed[0:6], dL/dexposure = packed[6:8] (the two inputs of PoseAdam.step) and the loss terms packed[8:11]."""
+    packed[TAU], dL/dexposure = packed[EXPOSURE_GRADS] (the two inputs of PoseTracker.step) and the loss terms packed[LOSS_TERMS]."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         work = dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
         return work if async_op else packed

@@ -129,9 +129,9 @@ int gsaj_rasterize_forward_async(int P, int D, int M, const float *bg, int W, in
                                  float *out_color, float *out_depth, float *out_opacity, int *radii, int *n_touched,
                                  void *geom_ws, void *binning_ws, size_t binning_ws_bytes, int capacity, int tile_list_capacity,
                                  void *image_ws, int flags /* GSAJ_FWD_* */, void *stream);
-/* Blocking: number of async forwards aborted on the device since the image workspace was zeroed by
- * the caller (the caller zero-fills the image workspace once, when it allocates it). */
-int gsaj_forward_aborted_count(int W, int H, const void *image_ws, void *stream, int *count /*host*/);
+/* Blocking: number of async forwards aborted on the device since the previous call (read and clear; the first call counts
+ * from when the caller zero-filled the image workspace, which it does once, when it allocates it). */
+int gsaj_forward_aborted_count(int W, int H, void *image_ws, void *stream, int *count /*host*/);
 
 /* Tile-band sharding of ONE frame (tracking on several GPUs; no counterpart in the reference, whose rasteriser is
  * single-device: cuda_rasterizer/rasterizer_impl.cu:224-352 binds every tile of the frame).  Every later forward that uses

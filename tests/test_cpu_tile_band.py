@@ -57,7 +57,7 @@ def test_pack_pose_terms_layout():
     tau = torch.arange(6, dtype=torch.float32)
     scalars = torch.tensor([10.0, 11.0, 12.0, 13.0, 14.0])  # loss, L_rgb, L_depth, dL/da, dL/db
     p = tbs.pack_pose_terms(tau, scalars)
-    assert p.tolist() == [0, 1, 2, 3, 4, 5, 13, 14, 10, 11, 12]
+    assert p.tolist() == [0, 1, 2, 3, 4, 5, 10, 11, 12, 13, 14]
     assert tbs.pack_pose_terms(tau).tolist() == [0, 1, 2, 3, 4, 5, 0, 0, 0, 0, 0]
     assert tbs.allreduce_pose_terms(p) is p  # no process group: identity
 
@@ -84,7 +84,7 @@ tau = torch.arange(6, dtype=torch.float32) * (rank + 1)
 scal = torch.tensor([1.0, 2.0, 3.0, 4.0, 5.0]) * (10 ** rank)
 packed = tbs.allreduce_pose_terms(tbs.pack_pose_terms(tau, scal))
 assert packed[0:6].tolist() == [0.0, 3.0, 6.0, 9.0, 12.0, 15.0]
-assert packed[6:8].tolist() == [44.0, 55.0] and packed[8:11].tolist() == [11.0, 22.0, 33.0]
+assert packed[tbs.EXPOSURE_GRADS].tolist() == [44.0, 55.0] and packed[tbs.LOSS_TERMS].tolist() == [11.0, 22.0, 33.0]
 work = tbs.allreduce_pose_terms(tbs.pack_pose_terms(tau), async_op=True)
 work.wait()
 dist.barrier(); dist.destroy_process_group()

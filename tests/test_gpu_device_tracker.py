@@ -1,0 +1,145 @@
+"""GPU: gsaj.tracking.DeviceTracker -- the tracking loop of a frame kept on the device, one iteration captured
+into a hipGraph and replayed.  The replayed loop must land on the SAME BITS as the eager sequence of C-ABI calls (same kernels,
+same launch parameters, same order), follow the whole-frame loop when the frame is sharded into tile bands, survive a new frame
+without re-capturing, and recover when a frame outgrows the arena."""
+import math
+
+import numpy as np
+import pytest
+
+import helpers as hp
+from gsaj import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(P=3000, W=160, H=120, seed=11):
+    import torch
+    from gsaj.rasterizer import FrameContext
+
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)  # noqa: E731
+    f = 0.875 * W
+    cam_gt = syn.fixture_camera(noisy=False, orthonormal=True, W=W, H=H, fx=f, fy=f, cx=W / 2 - 0.5, cy=H / 2 - 0.5)
+    cam0 = syn.fixture_camera(noisy=True, orthonormal=True, W=W, H=H, fx=f, fy=f, cx=W / 2 - 0.5, cy=H / 2 - 0.5)
+    sc = syn.make_scene(P, seed, cam_gt, z_range=(1.0, 4.0), log_scale_range=(math.log(0.02), math.log(0.1)))
+    M = sc["shs"].shape[1]
+    g = dict(means3D=t(sc["means3D"]), opacities=t(sc["opacities"]), shs=t(sc["shs"]), scales=t(sc["scales"]), rotations=t(sc["rotations"]),
+             sh_degree=3)
+    bg = torch.zeros(3, device=dev)
+    gt = FrameContext(P, W, H, M, dev)
+    gt.forward(bg, g["means3D"], g["opacities"], t(cam_gt["viewmatrix"]), t(cam_gt["projmatrix"]), t(cam_gt["campos"]), cam_gt["tanfovx"],
+               cam_gt["tanfovy"], sh_degree=3, shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
+    w2c0 = np.ascontiguousarray(cam0["viewmatrix"].T)
+    return dev, cam0, g, bg, gt.color.clone(), gt.depth[0].clone(), w2c0, M, t(cam0["projmatrix_raw"])
+
+
+def _tracker(dev, cam, g, bg, w2c, M, praw, **kw):
+    from gsaj.tracking import DeviceTracker
+
+    P = g["means3D"].shape[0]
+    return DeviceTracker(P, cam["W"], cam["H"], M, dev, w2c, praw, cam["tanfovx"], cam["tanfovy"], bg, alpha=0.9, **g, **kw)
+
+
+def test_graph_replay_equals_eager_bit_for_bit_and_converges():
+    import torch
+
+    dev, cam, g, bg, gt_c, gt_d, w2c0, M, praw = _setup()
+    out = {}
+    for use_graph in (False, True):
+        tr = _tracker(dev, cam, g, bg, w2c0, M, praw, use_graph=use_graph)
+        tr.set_frame(gt_c, gt_d)
+        losses = []
+        for _ in range(4):
+            assert tr.iterate(5) == 5
+            losses.append(float(tr.loss_terms[0]))
+        out[use_graph] = (tr.w2c.clone(), losses, tr.pose.state.clone())
+    assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][2], out[False][2])
+    assert out[True][1] == out[False][1]
+    assert out[True][1][-1] < 0.75 * out[True][1][0]  # 20 iterations (lr 1e-3 / 3e-3) towards the ground-truth pose: 0.133 -> 0.082
+
+
+def test_graph_replay_survives_host_synchronisation_between_replays():
+    """status() (a blocking read-back) or any other host synchronisation between two replays must not disturb the next one
+    (with hipMemsetAsync inside the captured forward it did on ROCm 7.2: the histogram was no longer cleared)."""
+    import torch
+
+    dev, cam, g, bg, gt_c, gt_d, w2c0, M, praw = _setup()
+    a = _tracker(dev, cam, g, bg, w2c0, M, praw, use_graph=True)
+    b = _tracker(dev, cam, g, bg, w2c0, M, praw, use_graph=False)
+    for tr in (a, b):
+        tr.set_frame(gt_c, gt_d)
+    for _ in range(6):
+        a.iterate(1)  # ends with status(): two blocking read-backs between consecutive replays
+        b.iterate(1)
+        torch.cuda.synchronize()
+        assert torch.equal(a.w2c, b.w2c)
+
+
+def test_new_frame_reuses_the_graph_and_reset_is_in_place():
+    import torch
+
+    dev, cam, g, bg, gt_c, gt_d, w2c0, M, praw = _setup()
+    tr = _tracker(dev, cam, g, bg, w2c0, M, praw, use_graph=True)
+    tr.set_frame(gt_c, gt_d)
+    tr.iterate(6)
+    first = tr.w2c.clone()
+    graphs = tr._graphs
+    assert graphs is not None
+    tr.set_frame(gt_c, gt_d, w2c=w2c0)  # same frame again from the same start: same result, same graph objects
+    tr.iterate(6)
+    assert tr._graphs is graphs
+    assert torch.equal(tr.w2c, first)
+    with pytest.raises(Exception, match="every frame"):
+        tr.set_frame(gt_c, None)
+
+
+def test_early_exit_on_the_device_converged_flag():
+    dev, cam, g, bg, gt_c, gt_d, w2c0, M, praw = _setup()
+    tr = _tracker(dev, cam, g, bg, w2c0, M, praw, converged_threshold=1e3)  # any step counts as converged
+    tr.set_frame(gt_c, gt_d)
+    assert tr.iterate(50, check_every=4) == 4
+
+
+def test_tile_band_shares_through_the_tracker_follow_the_whole_frame():
+    """Three trackers, one band each, stepped in lock step with their packed terms added by hand (what the all-reduce does):
+    the pose follows the single whole-frame tracker."""
+    import torch
+    from gsaj import tile_band_shard as tbs
+
+    dev, cam, g, bg, gt_c, gt_d, w2c0, M, praw = _setup()
+    whole = _tracker(dev, cam, g, bg, w2c0, M, praw, use_graph=False)
+    whole.set_frame(gt_c, gt_d)
+    whole.iterate(8)
+    parts = [_tracker(dev, cam, g, bg, w2c0, M, praw, use_graph=False, band=b) for b in tbs.uniform_bands(cam["H"], 3)]
+    for p in parts:
+        p.set_frame(gt_c, gt_d)
+    for it in range(8):
+        total = torch.zeros(tbs.REDUCED_FLOATS, device=dev)
+        for p in parts:
+            p._render_and_grads(it == 0)
+            total += p.packed  # (dL/dtau and the loss scalars were written straight into it)
+        for p in parts:
+            p.packed.copy_(total)
+            p._step()
+    for p in parts:
+        assert float((p.w2c - whole.w2c).abs().max()) < 2e-6
+    assert torch.equal(parts[0].w2c, parts[1].w2c)  # the replicas take the same step from the same sums
+
+
+def test_arena_overflow_is_reported_and_the_next_call_recovers():
+    import torch
+    from gsaj import _lib
+
+    dev, cam, g, bg, gt_c, gt_d, w2c0, M, praw = _setup()
+    tr = _tracker(dev, cam, g, bg, w2c0, M, praw, use_graph=True)
+    tr.set_frame(gt_c, gt_d)
+    tr.iterate(2)
+    good = tr.w2c.clone()
+    tr.ctx.capacity = 64  # pretend the arena was sized for a nearly empty view ...
+    tr._graphs = None     # ... before the graph was captured (launch arguments are frozen into a captured graph)
+    with pytest.raises(_lib.GsajError, match="aborted"):
+        tr.iterate(2)
+    tr.set_frame(gt_c, gt_d, w2c=w2c0)
+    assert tr.iterate(2) == 2  # re-sized by a synchronous first iteration, graph re-captured if the arena moved
+    assert torch.equal(tr.w2c, good)

@@ -248,8 +248,8 @@ def test_tracking_loop_on_band_shares_follows_the_whole_frame_loop():
                                 cam["tanfovy"], L["dL_dcolor"], L["dL_ddepth"], sh_degree=deg, pose_only=True, **kw)
                 packed += tbs.pack_pose_terms(g["tau_sum"], ls.scalars)  # what all-reduce(sum) does across ranks
             packed = tbs.allreduce_pose_terms(packed)  # single process: identity
-            pose.step(packed[0:6], packed[6:8])
-            losses.append(float(packed[8]))
+            pose.step(packed[tbs.TAU], packed[tbs.EXPOSURE_GRADS])
+            losses.append(float(packed[tbs.LOSS_TERMS][0]))
         return pose.w2c.clone(), losses
 
     w_whole, l_whole = loop([None])

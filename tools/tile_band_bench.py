@@ -52,7 +52,7 @@ def main():
             g = fc.backward(bg, means, pose.viewmatrix, pose.projmatrix, praw, pose.campos, cam["tanfovx"], cam["tanfovy"],
                             L["dL_dcolor"], L["dL_ddepth"], pose_only=True, **kw)
             tbs.pack_pose_terms(g["tau_sum"], ls.scalars, out=packed)
-            pose.step(packed[0:6], packed[6:8])
+            pose.step(packed[tbs.TAU], packed[tbs.EXPOSURE_GRADS])
 
         it(True)
         for _ in range(10):
