@@ -12,7 +12,7 @@ import torch
 from . import _lib
 
 _F32 = torch.float32
-FORCE_GLOBAL_SORT = False  # tests flip this to exercise the global radix-sort binning path
+FORCE_GLOBAL_SORT = bool(int(__import__("os").environ.get("GSAJ_FORCE_GLOBAL_SORT", "0")))  # tests flip this (or set the variable) to exercise the global radix-sort binning path
 SORT_CAP = 16384  # longest tile list the per-tile LDS sort handles (csrc/gsaj_common.h)
 
 
