@@ -7,7 +7,6 @@ import math
 import numpy as np
 import pytest
 
-import helpers as hp
 from gsaj import synthetic as syn
 
 pytestmark = pytest.mark.gpu
