@@ -272,6 +272,42 @@ __device__ __forceinline__ void gaussian_chain(const BwdParams &p, float3 mean, 
   if (p.scales && want_scale_rot) cov3d_backward(gcov, sc, q, p.scale_modifier, o.scale, o.rot);
 }
 
+// Four workgroups' dL/dtau partials (8 floats each, 6 used) as seen by ANOTHER workgroup after the ticket: 16-byte loads that
+// bypass this CU's L1 and this XCD's L2 (sc0 sc1).  The partials were stored write-through (agent-scope atomic stores) by CUs of
+// any XCD.  Coherent loads cost ~100 ns EACH on this part and do not overlap (tools/chain_trace.py: 6 dword loads per partial
+// made the last workgroup's sum 20 us of the batched kernel's 80; two dwordx4 loads: 8 us), so they are as wide as the ISA allows,
+// eight to a batch, and the batch's s_waitcnt sits in the SAME asm statement: the compiler takes an asm's outputs for ready when
+// the statement ends and may copy them at once.
+__device__ __forceinline__ void gsaj_load_partials4(const float *p0, const float *p1, const float *p2, const float *p3,
+                                                    float4 (&lo)[4], float4 (&hi)[4]) {
+  asm volatile(
+      "global_load_dwordx4 %0, %8, off sc0 sc1\n\tglobal_load_dwordx4 %1, %8, off offset:16 sc0 sc1\n\t"
+      "global_load_dwordx4 %2, %9, off sc0 sc1\n\tglobal_load_dwordx4 %3, %9, off offset:16 sc0 sc1\n\t"
+      "global_load_dwordx4 %4, %10, off sc0 sc1\n\tglobal_load_dwordx4 %5, %10, off offset:16 sc0 sc1\n\t"
+      "global_load_dwordx4 %6, %11, off sc0 sc1\n\tglobal_load_dwordx4 %7, %11, off offset:16 sc0 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(lo[0]), "=&v"(hi[0]), "=&v"(lo[1]), "=&v"(hi[1]), "=&v"(lo[2]), "=&v"(hi[2]), "=&v"(lo[3]), "=&v"(hi[3])
+      : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+      : "memory");
+}
+// sum over workgroups i = lane, lane + 64, ... < nblk of the 6 components, in that order, in fp64
+__device__ __forceinline__ void gsaj_sum_partials(const float *partials, int nblk, int lane, double (&acc)[6]) {
+  for (int i0 = lane; i0 < nblk; i0 += 4 * 64) {
+    float4 lo[4], hi[4];
+    const float *src[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) src[u] = partials + (size_t)min(i0 + u * 64, nblk - 1) * 8;  // unconditional loads, masked below
+    gsaj_load_partials4(src[0], src[1], src[2], src[3], lo, hi);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const bool in = i0 + u * 64 < nblk;
+      const float t6[6] = {lo[u].x, lo[u].y, lo[u].z, lo[u].w, hi[u].x, hi[u].y};
+#pragma unroll
+      for (int k = 0; k < 6; k++) acc[k] += in ? (double)t6[k] : 0.0;
+    }
+  }
+}
+
 // SHW = 3*M as a compile-time constant (0: runtime) -- the staging loops divide by it per element
 GSAJ_TRACE_DEFINE(gbwd)
 
@@ -424,22 +460,7 @@ __global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g
   if (s_ticket == gridDim.x - 1) {
   const int nblk = (int)gridDim.x;
   double acc6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  for (int i0 = tid; i0 < nblk; i0 += 4 * GB_BLOCK) {  // 24 independent loads in flight per trip, summed in row order
-    float v[4][6];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int i = i0 + u * GB_BLOCK, ic = min(i, nblk - 1);  // unconditional loads (a guarded atomic load becomes a
-#pragma unroll                                                       // branch + s_waitcnt vmcnt(0) each), masked afterwards
-      for (int k = 0; k < 6; k++) {
-        const float t = __hip_atomic_load(&g.tau_partials[(size_t)ic * 8 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        v[u][k] = i < nblk ? t : 0.f;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++)
-#pragma unroll
-      for (int k = 0; k < 6; k++) acc6[k] += (double)v[u][k];
-  }
+  gsaj_sum_partials(g.tau_partials, nblk, tid, acc6);
 #pragma unroll
   for (int k = 0; k < 6; k++) {
     double v = acc6[k];
@@ -627,6 +648,7 @@ __global__ __launch_bounds__(256) void k_gather_sums(int P, const int *__restric
   (void)radii0;
 }
 
+GSAJ_TRACE_DEFINE(gbb)
 #define GBB_MAX_WAVES 4  // measured at K = 8, cfg2: 2 waves 118 us, 4 waves 79 us, 8 waves 94 us (two workgroups per CU overlap their serial phases)
 template <int SHW>
 __global__ __launch_bounds__(GB_BLOCK * GBB_MAX_WAVES) void k_gaussian_bwd_batch(BwdParams p, int K, GeomWS g0, ImageWS im0,
@@ -636,6 +658,13 @@ __global__ __launch_bounds__(GB_BLOCK * GBB_MAX_WAVES) void k_gaussian_bwd_batch
                                                                                  float *__restrict__ pv_color, float *__restrict__ pv_depth,
                                                                                  float *__restrict__ pv_tau, int accumulate) {
   constexpr int NACC = 17 + SHW;  // opacity, mean3D 3, cov3D 6, scale 3, rot 4, dL/dSH
+  GSAJ_TRACE_BEGIN(gbb)
+#ifdef GSAJ_BLOCK_TRACE
+  unsigned long long trb_[6] = {0, 0, 0, 0, 0, 0}, trb_t = wall_clock64();
+#define TRB(i) { const unsigned long long n_ = wall_clock64(); trb_[i] += n_ - trb_t; trb_t = n_; }
+#else
+#define TRB(i)
+#endif
   constexpr int MC = SHW / 3;     // SH coefficients stored
   constexpr int shs_stride = SHW + 1;
   extern __shared__ float lds_dyn[];  // [64][SHW+1] SH coefficients | [NW][NACC][64] per-wave sums (component-major: conflict-free)
@@ -667,6 +696,7 @@ __global__ __launch_bounds__(GB_BLOCK * GBB_MAX_WAVES) void k_gaussian_bwd_batch
     }
   }
   __syncthreads();
+  TRB(0)  // inputs + SH staging + barrier
   const float *vm0 = p.viewmatrix, *pj0 = p.projmatrix, *cam0 = p.campos;
   const int *radii0 = p.radii;
   for (int v0 = 0; v0 < K; v0 += NW) {
@@ -695,6 +725,10 @@ __global__ __launch_bounds__(GB_BLOCK * GBB_MAX_WAVES) void k_gaussian_bwd_batch
       // the Gaussian's 10 reverse-compositor sums of this view (k_gather_sums)
       const float4 s0 = g.gsum[3 * ii + 0], s1 = g.gsum[3 * ii + 1], s2 = g.gsum[3 * ii + 2];
       float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#ifdef GSAJ_BLOCK_TRACE
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+      TRB(1)  // this view's loads
       if (vis) {
         // (dL/dscale, dL/drot are linear in dL/dcov3D with view-independent coefficients: formed ONCE below from the sum over views)
         gaussian_chain<true>(p, mean, c6, sc, q, cl, s0, s1, s2, sh_in + tid * shs_stride, shw, false, o, tau);
@@ -720,6 +754,7 @@ __global__ __launch_bounds__(GB_BLOCK * GBB_MAX_WAVES) void k_gaussian_bwd_batch
         if (tid == 0) __hip_atomic_store(&g.tau_partials[(size_t)blockIdx.x * 8 + k], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
+    TRB(2)  // chain + per-view outputs + tau butterfly
     // ---- this view is added to the wave's private sums (no other wave touches them) ----
     if (v < K) {
       const bool first_view = v0 == 0;  // (every wave has a view in the first round: NW <= K) stores instead of adds: no zero fill
@@ -738,6 +773,7 @@ __global__ __launch_bounds__(GB_BLOCK * GBB_MAX_WAVES) void k_gaussian_bwd_batch
 #undef MADD
     }
   }
+  TRB(3)  // LDS sums
   // ---- the waves' sums are added in wave order, every (component, Gaussian) by one thread: fixed order, bit-reproducible ----
   __syncthreads();
   for (int e = threadIdx.x; e < NACC * CS; e += (int)blockDim.x) {
@@ -746,20 +782,21 @@ __global__ __launch_bounds__(GB_BLOCK * GBB_MAX_WAVES) void k_gaussian_bwd_batch
     meet_all[e] = t;
   }
   __syncthreads();
+  TRB(4)  // barrier (waiting for the slowest wave) + cross-wave sums
   // ---- dL/dtau: the last workgroup to arrive sums every view's partials in workgroup order (fp64) ----
   if (threadIdx.x == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     s_ticket = __hip_atomic_fetch_add(&im0.counters[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
+  TRB(4)  // (+ ticket)
   if (s_ticket == gridDim.x - 1 && p.dL_dtau_sum) {
     const int nblk = (int)gridDim.x;
     for (int v = wave; v < K; v += NW) {
       const float *tp = gsaj_shift(g0.tau_partials, (size_t)v * vs.geom);
       double a6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-      for (int i = tid; i < nblk; i += 64)
-#pragma unroll
-        for (int k = 0; k < 6; k++) a6[k] += (double)__hip_atomic_load(&tp[(size_t)i * 8 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // This workgroup works alone while the rest of the chip waits for the kernel to end (gsaj_load_partial); summed in workgroup order.
+      gsaj_sum_partials(tp, nblk, tid, a6);
 #pragma unroll
       for (int k = 0; k < 6; k++) {
         double t = a6[k];
@@ -770,6 +807,7 @@ __global__ __launch_bounds__(GB_BLOCK * GBB_MAX_WAVES) void k_gaussian_bwd_batch
     }
     if (threadIdx.x == 0) im0.counters[3] = 0u;
   }
+  TRB(5)  // (+ the last workgroup's dL/dtau sums)
   // ---- outputs, once per Gaussian ----
   if (wave == 0 && idx < p.P) {
 #define MGET(k) meet_all[(k) * CS + tid]
@@ -805,6 +843,17 @@ __global__ __launch_bounds__(GB_BLOCK * GBB_MAX_WAVES) void k_gaussian_bwd_batch
       p.dL_dsh[base + e] = accumulate ? p.dL_dsh[base + e] + t : t;
     }
   }
+  GSAJ_TRACE_END(gbb)
+#ifdef GSAJ_BLOCK_TRACE
+  {
+    const unsigned tw_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if ((threadIdx.x & 63) == 0 && tw_ < GSAJ_TRACE_MAX) {
+      g_trace_gbb[4 * tw_ + 2] = (trb_[0] << 42) | (trb_[1] << 21) | trb_[2];
+      g_trace_gbb[4 * tw_ + 3] = (trb_[3] << 42) | (trb_[4] << 21) | trb_[5];
+    }
+  }
+#endif
+#undef TRB
 }
 
 template <int SHW>
