@@ -687,6 +687,27 @@ __global__ __launch_bounds__(GB_BLOCK * GBB_MAX_WAVES) void k_gaussian_bwd_batch
     sc = make_float3(p.scales[3 * ii], p.scales[3 * ii + 1], p.scales[3 * ii + 2]);
     q = reinterpret_cast<const float4 *>(p.rotations)[ii];
   }
+  // A view's inputs for this Gaussian: radius, abort flag, clamp flags and the 10 gathered sums -- all requested together and
+  // unconditionally (a load that waits for another load's result costs a second ~2 us round trip at two waves per SIMD), and one
+  // view AHEAD: the first view's before the SH staging below, view v + NW's before the chain of view v.
+  struct ViewIn {
+    uint32_t ab;
+    int rad;
+    uint8_t cl[3];
+    float4 s0, s1, s2;
+  };
+  const int *radii0 = p.radii;
+  auto request = [&](int v, ViewIn &in) {
+    const int vc = min(v, K - 1);
+    const GeomWS g = geom_view(g0, (size_t)vc * vs.geom);
+    in.ab = gsaj_shift(im0.counters, (size_t)vc * vs.image)[4];
+    in.rad = radii0[(size_t)vc * p.P + ii];
+    in.cl[0] = in.cl[1] = in.cl[2] = 0;
+    if (SHW > 0) { in.cl[0] = g.clamped[3 * ii]; in.cl[1] = g.clamped[3 * ii + 1]; in.cl[2] = g.clamped[3 * ii + 2]; }
+    in.s0 = g.gsum[3 * ii + 0]; in.s1 = g.gsum[3 * ii + 1]; in.s2 = g.gsum[3 * ii + 2];
+  };
+  ViewIn nxt;
+  request(wave, nxt);
   if (SHW > 0) {  // coalesced load of the workgroup's contiguous [64][M*3] SH block
     const size_t base = (size_t)blockIdx.x * GB_BLOCK * SHW;
     const int count = min(GB_BLOCK, p.P - blockIdx.x * GB_BLOCK) * SHW;
@@ -698,9 +719,10 @@ __global__ __launch_bounds__(GB_BLOCK * GBB_MAX_WAVES) void k_gaussian_bwd_batch
   __syncthreads();
   TRB(0)  // inputs + SH staging + barrier
   const float *vm0 = p.viewmatrix, *pj0 = p.projmatrix, *cam0 = p.campos;
-  const int *radii0 = p.radii;
   for (int v0 = 0; v0 < K; v0 += NW) {
     const int v = v0 + wave;
+    const ViewIn cur = nxt;
+    if (v0 + NW < K) request(v + NW, nxt);
     GaussianGrads o;
     o.m2x = o.m2y = o.ca = o.cb = o.cc = o.op = o.dz = 0.f;
     o.col = o.gm = o.scale = make_float3(0.f, 0.f, 0.f);
@@ -713,17 +735,15 @@ __global__ __launch_bounds__(GB_BLOCK * GBB_MAX_WAVES) void k_gaussian_bwd_batch
     float gmask[3] = {0.f, 0.f, 0.f};
     if (v < K) {
       const GeomWS g = geom_view(g0, (size_t)v * vs.geom);
-      const uint32_t *counters = gsaj_shift(im0.counters, (size_t)v * vs.image);
       p.viewmatrix = vm0 + 16 * v;
       p.projmatrix = pj0 + 16 * v;
       p.campos = cam0 ? cam0 + 3 * v : nullptr;
-      const bool aborted = counters[4] != 0u;  // aborted async frame: contributes nothing
-      const int radius = (idx < p.P && !aborted) ? radii0[(size_t)v * p.P + ii] : 0;
+      const bool aborted = cur.ab != 0u;  // aborted async frame: contributes nothing
+      const int radius = (idx < p.P && !aborted) ? cur.rad : 0;
       const bool vis = radius > 0;
-      uint8_t cl[3] = {0, 0, 0};
-      if (SHW > 0) { cl[0] = g.clamped[3 * ii]; cl[1] = g.clamped[3 * ii + 1]; cl[2] = g.clamped[3 * ii + 2]; }
+      const uint8_t cl[3] = {cur.cl[0], cur.cl[1], cur.cl[2]};
       // the Gaussian's 10 reverse-compositor sums of this view (k_gather_sums)
-      const float4 s0 = g.gsum[3 * ii + 0], s1 = g.gsum[3 * ii + 1], s2 = g.gsum[3 * ii + 2];
+      const float4 s0 = cur.s0, s1 = cur.s1, s2 = cur.s2;
       float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #ifdef GSAJ_BLOCK_TRACE
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
