@@ -567,9 +567,11 @@ __device__ __forceinline__ void scan_by_key_step(int own, float (&v)[10]) {
 // from its segment's last row of the group.  No LDS staging, no per-lane loop over a heavy-tailed run length (that loop kept ~20 % of
 // the lanes busy and its scattered ds_read_b128 conflicted 4-way: 100 us; this form: see profiles/).  The additions follow a
 // fixed tree per 64-row group and the groups in order: bit-reproducible.
+GSAJ_TRACE_DEFINE(gath)
 __global__ __launch_bounds__(256) void k_gather_sums(int P, const int *__restrict__ radii0, GeomWS g0, ImageWS im0,
                                                      const float4 *__restrict__ inst_grad0, const uint8_t *__restrict__ reached0,
                                                      ViewStrides vs) {
+  GSAJ_TRACE_BEGIN(gath)
   const size_t view = blockIdx.y;
   const GeomWS g = geom_view(g0, view * vs.geom);
   const float4 *inst_grad = gsaj_shift(inst_grad0, view * vs.bin);
@@ -646,6 +648,7 @@ __global__ __launch_bounds__(256) void k_gather_sums(int P, const int *__restric
     g.gsum[3 * ii + 2] = make_float4(sum[8], sum[9], 0.f, 0.f);
   }
   (void)radii0;
+  GSAJ_TRACE_END(gath)
 }
 
 GSAJ_TRACE_DEFINE(gbb)

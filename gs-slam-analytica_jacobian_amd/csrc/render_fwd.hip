@@ -19,9 +19,19 @@
 #define FWD_CHUNK 64  // records staged per wave per trip
 #define FWD_PAD 8     // inert records after the packed ones: the pipelined entry loop reads up to 7 slots past the last
 
+// Workgroup shape.  The four quadrant waves of a tile never talk to each other (no barrier, private LDS areas), so each can be
+// its own 64-thread workgroup: a 256-thread workgroup holds its CU slots until its SLOWEST wave is done, and the quadrants of a
+// tile finish far apart (per-wave trace of a batched window, tools/batch_trace.py: mean wave life 27 us, 4045 of 5120 wave slots
+// busy on average).  Wave-sized workgroups give every finished wave's slot back at once.  The quadrants of a tile keep
+// blockIdx.x equal mod 8, i.e. on the same XCD, so that the tile's records are fetched into ONE L2.
+#ifndef GSAJ_FWD_THREADS
+#define GSAJ_FWD_THREADS 64
+#endif
+#define FWD_WAVES (GSAJ_FWD_THREADS / 64)
+
 GSAJ_TRACE_DEFINE(fwd)
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_render_fwd(int W, int H, int gx, int P, ImageWS im,
+__global__ __launch_bounds__(GSAJ_FWD_THREADS) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_render_fwd(int W, int H, int gx, int tiles, int P, ImageWS im,
                                                     const float4 *__restrict__ records, const float *__restrict__ bg,
                                                     float *__restrict__ out_color, float *__restrict__ out_depth,
                                                     float *__restrict__ out_opacity, int *__restrict__ n_touched,
@@ -44,15 +54,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
   // Each wave (one 8x8 quadrant) walks the tile list on its own: private 64-record staging area, no
   // workgroup barrier anywhere, so a quadrant never waits for a slower neighbour.  The four waves of a
   // tile read the same records; the repeats are served by L1/L2.
-  __shared__ float4 rec_all[4 * (FWD_CHUNK + FWD_PAD) * REC_F4];
-  __shared__ uint32_t waves_done;
+  __shared__ float4 rec_all[FWD_WAVES * (FWD_CHUNK + FWD_PAD) * REC_F4];
   if (counters[4]) return;  // aborted async frame
-  if (threadIdx.x == 0) waves_done = 0u;
-  __syncthreads();  // the only workgroup barrier: the counter is initialised before any wave can finish
   GSAJ_TRACE_BEGIN(fwd)
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  float4 *rec = rec_all + wave * (FWD_CHUNK + FWD_PAD) * REC_F4;
+  const int tid = threadIdx.x, lane = tid & 63;
+#if FWD_WAVES == 1
+  // 32 consecutive workgroups = 8 tiles x 4 quadrants; tile slot = blockIdx.x & 7 (the XCD the workgroup lands on)
+  const int wave = ((int)blockIdx.x >> 3) & 3;
+  const int tile = ((int)blockIdx.x >> 5) * 8 + ((int)blockIdx.x & 7);
+  if (tile >= tiles) return;
+  float4 *rec = rec_all;
+#else
+  const int wave = tid >> 6;
   const int tile = blockIdx.x;
+  float4 *rec = rec_all + wave * (FWD_CHUNK + FWD_PAD) * REC_F4;
+#endif
   const int ty = tile / gx, tx = tile - ty * gx;
   const int px = tx * TILE + (wave & 1) * 8 + (lane & 7);
   const int py = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
@@ -177,7 +193,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
   }
   // Tiles are listed in the order their workgroups finish: the reverse compositor walks that list backwards, so the
   // tiles that kept a quadrant busy longest (deepest last contributor = most backward work) start first there.
-  if (lane == 0 && atomicAdd(&waves_done, 1u) == 3u) finish_list[atomicAdd(&counters[6], 1u)] = (uint32_t)tile;
+  if (lane == 0 && atomicAdd(&im.tile_done[tile], 1u) == 3u) finish_list[atomicAdd(&counters[6], 1u)] = (uint32_t)tile;
   GSAJ_TRACE_END(fwd)
 }
 
@@ -186,7 +202,9 @@ int launch_render_forward(int P, int W, int H, int grid_x, int grid_y, const flo
                           hipStream_t s) {
   {
     GsajProfScope ps(ST_RENDER_FWD, s);
-    hipLaunchKernelGGL(k_render_fwd, dim3(grid_x * grid_y, views), dim3(256), 0, s, W, H, grid_x, P, im, b.records, bg, out_color,
+    const int tiles = grid_x * grid_y;
+    const unsigned nblk = FWD_WAVES == 1 ? (unsigned)((tiles + 7) / 8) * 32u : (unsigned)tiles;
+    hipLaunchKernelGGL(k_render_fwd, dim3(nblk, views), dim3(GSAJ_FWD_THREADS), 0, s, W, H, grid_x, tiles, P, im, b.records, bg, out_color,
                        out_depth, out_opacity, n_touched, b.point_list, vs);
   }
   GSAJ_HIP_CHECK(hipGetLastError());
