@@ -87,12 +87,11 @@ struct ImageWS {  // reference: ImageState, rasterizer_impl.h:46-53
   uint2 *ranges;          // [tiles]
   uint32_t *counters;     // [N_COUNTERS]            -+
   uint32_t *tile_count;   // [tiles*TILE_REP]         | zeroed by ONE memset per forward
-  uint32_t *tile_cursor;  // [tiles*TILE_REP]         |
-  uint32_t *tile_done;    // [tiles] forward waves of the tile that have finished (4 = the tile goes on the finish list) -+
+  uint32_t *tile_cursor;  // [tiles*TILE_REP]        -+
   uint32_t *tile_offset;  // [tiles*TILE_REP + 1] exclusive scan of tile_count (tile-major)
   uint32_t *sticky;       // [16] never zeroed by a forward: [0] number of aborted async forwards, [1] tile band, [2] its complement (gsaj_tile_band)
-  uint32_t *finish_list;  // [tiles] tile indices in the order their forward workgroups finished (counters[6] = how many)
-  size_t zero_bytes;      // bytes from counters to the end of tile_done
+  uint32_t *tile_order;   // [tiles] tile indices, longest list first (frame_scan): the order both compositors take their tiles in
+  size_t zero_bytes;      // bytes from counters to the end of tile_cursor
 };
 
 static inline __host__ __device__ size_t image_carve(char *base, int W, int H, ImageWS *s) {
@@ -107,11 +106,10 @@ static inline __host__ __device__ size_t image_carve(char *base, int W, int H, I
   CARVE(counters, uint32_t, N_COUNTERS);
   CARVE(tile_count, uint32_t, tiles * TILE_REP);
   CARVE(tile_cursor, uint32_t, tiles * TILE_REP);
-  CARVE(tile_done, uint32_t, tiles);
   if (g) g->zero_bytes = off - z0;
   CARVE(tile_offset, uint32_t, tiles * TILE_REP + 1);
   CARVE(sticky, uint32_t, 16);
-  CARVE(finish_list, uint32_t, tiles);
+  CARVE(tile_order, uint32_t, tiles);
   return off;
 }
 
@@ -149,8 +147,8 @@ __device__ __forceinline__ GeomWS geom_view(GeomWS g, size_t off) {
 __device__ __forceinline__ ImageWS image_view(ImageWS m, size_t off) {
   m.final_T = gsaj_shift(m.final_T, off); m.n_contrib = gsaj_shift(m.n_contrib, off); m.ranges = gsaj_shift(m.ranges, off);
   m.counters = gsaj_shift(m.counters, off); m.tile_count = gsaj_shift(m.tile_count, off);
-  m.tile_cursor = gsaj_shift(m.tile_cursor, off); m.tile_done = gsaj_shift(m.tile_done, off); m.tile_offset = gsaj_shift(m.tile_offset, off);
-  m.sticky = gsaj_shift(m.sticky, off); m.finish_list = gsaj_shift(m.finish_list, off);
+  m.tile_cursor = gsaj_shift(m.tile_cursor, off); m.tile_offset = gsaj_shift(m.tile_offset, off);
+  m.sticky = gsaj_shift(m.sticky, off); m.tile_order = gsaj_shift(m.tile_order, off);
   return m;
 }
 #endif

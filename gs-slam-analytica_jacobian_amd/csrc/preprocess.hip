@@ -103,7 +103,7 @@ __device__ __forceinline__ float3 sh_to_rgb(int deg, float3 pos, float3 campos, 
   return make_float3(out[0], out[1], out[2]);
 }
 
-__device__ void frame_scan(int nblk, int tiles, int capacity, int sort_cap, uint32_t *block_sums, ImageWS im);
+__device__ void frame_scan(int nblk, int tiles, int capacity, int sort_cap, uint32_t *block_sums, ImageWS im, uint32_t *lds_tiles);
 
 GSAJ_TRACE_DEFINE(pre)
 
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__re
     s_last = __hip_atomic_fetch_add(&im.counters[5], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
   __syncthreads();
   TRP(2)
-  if (s_last) frame_scan((int)gridDim.x, tiles, p.capacity, p.sort_cap, g.block_sums, im);
+  if (s_last) frame_scan((int)gridDim.x, tiles, p.capacity, p.sort_cap, g.block_sums, im, use_lds ? hist : nullptr);
   TRP(3)
   GSAJ_TRACE_END(pre)
 #ifdef GSAJ_BLOCK_TRACE
@@ -323,14 +323,99 @@ __device__ uint32_t tail_exclusive_scan(const uint32_t *in, uint32_t *out, int n
   return total;
 }
 
+// Four consecutive words written by OTHER workgroups of this launch (L2 atomics / write-through stores): one 16-byte load that
+// bypasses this CU's L1 and this XCD's L2.  Coherent loads cost ~100 ns each and do not overlap (see gsaj_sum_partials in
+// gaussian_bwd.hip), so the tail code below uses as few and as wide ones as it can.
+__device__ __forceinline__ uint4 coherent_load_x4(const uint32_t *src) {
+  uint4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(src) : "memory");
+  return v;
+}
+
+// The per-tile histogram the other workgroups flushed -> (1) its exclusive scan (tile_offset), (2) the longest list, (3) the order
+// in which both compositors take their tiles: longest list first (64 length classes, counting sort in LDS).  A launch that
+// oversubscribes the chip (a batched window: 9600 tiles for 1280 workgroup slots) then ends on its short tiles instead of waiting
+// for a long one dispatched last; a single frame, resident as a whole, does not care.  The order inside a length class is whatever
+// the LDS atomics give -- it changes which workgroup runs where, never a result.  `len`: the histogram copied ONCE into LDS
+// ([tiles], the dead workgroup-local histogram area) with wide coherent loads; every later pass reads LDS.
+__device__ uint32_t tile_scan_and_schedule(int tiles, ImageWS im, uint32_t *len, uint32_t *longest_out) {
+  __shared__ uint32_t wsum[PRE_BLOCK / 64], wmax[PRE_BLOCK / 64], cls[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int c = tid; 4 * c < tiles; c += PRE_BLOCK) {  // (reads up to 3 words past `tiles`: still inside the zeroed counter block)
+    const uint4 v = coherent_load_x4(im.tile_count + 4 * c);
+    len[4 * c] = v.x;
+    if (4 * c + 1 < tiles) len[4 * c + 1] = v.y;
+    if (4 * c + 2 < tiles) len[4 * c + 2] = v.z;
+    if (4 * c + 3 < tiles) len[4 * c + 3] = v.w;
+  }
+  if (tid < 64) cls[tid] = 0u;
+  __syncthreads();
+  // (1) + (2): each lane owns a contiguous run, run totals scanned with wave shuffles + one LDS hop
+  const int per = (tiles + PRE_BLOCK - 1) / PRE_BLOCK;
+  const int b0 = min(tiles, tid * per), b1 = min(tiles, b0 + per);
+  uint32_t s = 0, mx = 0;
+  for (int i = b0; i < b1; i++) {
+    s += len[i];
+    mx = max(mx, len[i]);
+  }
+  uint32_t incl = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t v = __shfl_up((int)incl, o);
+    if (lane >= o) incl += v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+  if (lane == 63) wsum[wave] = incl;
+  if (lane == 0) wmax[wave] = mx;
+  __syncthreads();
+  uint32_t woff = 0, total = 0, longest = 0;
+#pragma unroll
+  for (int w = 0; w < PRE_BLOCK / 64; w++) {
+    const uint32_t v = wsum[w];
+    if (w < wave) woff += v;
+    total += v;
+    longest = max(longest, wmax[w]);
+  }
+  uint32_t run = woff + incl - s;
+  for (int i = b0; i < b1; i++) {
+    im.tile_offset[i] = run;
+    run += len[i];
+  }
+  // (3)
+  const int shift = longest >= 64u ? (32 - __builtin_clz(longest)) - 6 : 0;  // longest >> shift <= 63
+  for (int t = tid; t < tiles; t += PRE_BLOCK) atomicAdd(&cls[63u - min(63u, len[t] >> shift)], 1u);
+  __syncthreads();
+  if (tid < 64) {  // exclusive scan of the 64 class sizes by one wave
+    const uint32_t v = cls[tid];
+    uint32_t in2 = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t u = (uint32_t)__shfl_up((int)in2, o);
+      if (tid >= o) in2 += u;
+    }
+    cls[tid] = in2 - v;
+  }
+  __syncthreads();
+  for (int t = tid; t < tiles; t += PRE_BLOCK) im.tile_order[atomicAdd(&cls[63u - min(63u, len[t] >> shift)], 1u)] = (uint32_t)t;
+  __syncthreads();
+  *longest_out = longest;
+  return total;
+}
+
 // Run by the LAST workgroup of k_preprocess to arrive (replaces cub::DeviceScan of
 // rasterizer_impl.cu:327 and a separate launch): (1) exclusive offsets of the per-workgroup Gaussian
 // totals and the grand total R; (2) exclusive offsets of the per-tile histogram; (3) the longest
 // tile list; (4) for the async forward, the device-side capacity check.
-__device__ void frame_scan(int nblk, int tiles, int capacity, int sort_cap, uint32_t *block_sums, ImageWS im) {
+__device__ void frame_scan(int nblk, int tiles, int capacity, int sort_cap, uint32_t *block_sums, ImageWS im, uint32_t *lds_tiles) {
   const uint32_t R = tail_exclusive_scan(block_sums, block_sums, nblk, nullptr);
-  uint32_t m = 0;
-  const uint32_t R2 = tail_exclusive_scan(im.tile_count, im.tile_offset, tiles, &m);
+  uint32_t m = 0, R2;
+  if (lds_tiles) {
+    R2 = tile_scan_and_schedule(tiles, im, lds_tiles, &m);
+  } else {  // more tiles than the LDS histogram holds (> 8192: beyond 2048 x 1024 pixels): scan from memory, tiles in index order
+    R2 = tail_exclusive_scan(im.tile_count, im.tile_offset, tiles, &m);
+    for (int t = threadIdx.x; t < tiles; t += PRE_BLOCK) im.tile_order[t] = (uint32_t)t;
+  }
   if (threadIdx.x == 0) {
     im.tile_offset[tiles] = R2;
     im.counters[0] = R;

@@ -29,7 +29,7 @@
 //  Gaussian's rows in a fixed order, so gradients are bit-reproducible run to run (the reference's
 //  float atomics are not).  Entries beyond the quadrant's / tile's furthest last-contributor are
 //  never visited; those beyond the tile's get a one-byte `reached = 0` flag instead of a zero row.
-//  Workgroups take tiles in reverse order of the forward's finish list (longest tiles first).
+//  Workgroups take tiles longest list first (ImageWS.tile_order, written by the preprocess kernel's frame scan).
 #include "gsaj_common.h"
 #include "wave_reduce.h"
 
@@ -58,7 +58,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
   const uint2 *__restrict__ ranges = im.ranges;
   const float *__restrict__ final_T = im.final_T;
   const uint32_t *__restrict__ n_contrib = im.n_contrib;
-  const uint32_t *__restrict__ finish_list = im.finish_list;
   const uint32_t *__restrict__ counters = im.counters;
   __shared__ float4 rec[BWD_ROUND * REC_F4];
   __shared__ __attribute__((aligned(16))) float acc[4 * ACC_C * ACC_STRIDE];  // [wave][partial][entry]
@@ -70,8 +69,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   float2 *wu = wu_all + wave * SLOTS * WU_STRIDE;
   float4 *seed = seed_all + wave * 64;
-  // longest-running forward tiles first (clamped: a stale list must not become an out-of-range tile)
-  const int tile = __builtin_amdgcn_readfirstlane((int)min(finish_list[gridDim.x - 1 - blockIdx.x], gridDim.x - 1));
+  // longest lists first (frame_scan's schedule; clamped: a stale entry must not become an out-of-range tile)
+  const int tile = __builtin_amdgcn_readfirstlane((int)min(im.tile_order[blockIdx.x], gridDim.x - 1));
   const int ty = tile / gx, tx = tile - ty * gx;
   const int px = tx * TILE + (wave & 1) * 8 + (lane & 7);
   const int py = ty * TILE + (wave >> 1) * 8 + (lane >> 3);

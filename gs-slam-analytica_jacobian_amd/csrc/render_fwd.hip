@@ -12,7 +12,7 @@
 // weight 0 instead of branching.  Early-outs are wave-level ballots (a quadrant whose 64 pixels have all saturated
 // stops), not the reference's block-wide votes.  n_touched: lane l counts packed entry l, only while some pixel of the
 // quadrant still has T > 0.5, and ONE atomic wave-instruction per 64 entries flushes it (the reference issues one
-// atomic per pixel per entry, forward.cu:512-514).  The order in which tiles finish is recorded for the backward.
+// atomic per pixel per entry, forward.cu:512-514).  Tiles are taken longest list first (ImageWS.tile_order).
 #include "gsaj_common.h"
 #include "wave_reduce.h"
 
@@ -50,7 +50,6 @@ __global__ __launch_bounds__(GSAJ_FWD_THREADS) __attribute__((amdgpu_waves_per_e
   float *__restrict__ final_T = im.final_T;
   uint32_t *__restrict__ n_contrib = im.n_contrib;
   uint32_t *__restrict__ counters = im.counters;
-  uint32_t *__restrict__ finish_list = im.finish_list;
   // Each wave (one 8x8 quadrant) walks the tile list on its own: private 64-record staging area, no
   // workgroup barrier anywhere, so a quadrant never waits for a slower neighbour.  The four waves of a
   // tile read the same records; the repeats are served by L1/L2.
@@ -61,12 +60,13 @@ __global__ __launch_bounds__(GSAJ_FWD_THREADS) __attribute__((amdgpu_waves_per_e
 #if FWD_WAVES == 1
   // 32 consecutive workgroups = 8 tiles x 4 quadrants; tile slot = blockIdx.x & 7 (the XCD the workgroup lands on)
   const int wave = ((int)blockIdx.x >> 3) & 3;
-  const int tile = ((int)blockIdx.x >> 5) * 8 + ((int)blockIdx.x & 7);
-  if (tile >= tiles) return;
+  const int rank = ((int)blockIdx.x >> 5) * 8 + ((int)blockIdx.x & 7);
+  if (rank >= tiles) return;
+  const int tile = (int)min(im.tile_order[rank], (uint32_t)(tiles - 1));  // longest lists first (frame_scan)
   float4 *rec = rec_all;
 #else
   const int wave = tid >> 6;
-  const int tile = blockIdx.x;
+  const int tile = (int)min(im.tile_order[blockIdx.x], (uint32_t)(tiles - 1));
   float4 *rec = rec_all + wave * (FWD_CHUNK + FWD_PAD) * REC_F4;
 #endif
   const int ty = tile / gx, tx = tile - ty * gx;
@@ -191,9 +191,6 @@ __global__ __launch_bounds__(GSAJ_FWD_THREADS) __attribute__((amdgpu_waves_per_e
     out_depth[pid] = Dp;
     out_opacity[pid] = 1.f - T;
   }
-  // Tiles are listed in the order their workgroups finish: the reverse compositor walks that list backwards, so the
-  // tiles that kept a quadrant busy longest (deepest last contributor = most backward work) start first there.
-  if (lane == 0 && atomicAdd(&im.tile_done[tile], 1u) == 3u) finish_list[atomicAdd(&counters[6], 1u)] = (uint32_t)tile;
   GSAJ_TRACE_END(fwd)
 }
 
