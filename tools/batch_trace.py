@@ -17,14 +17,15 @@ from gsaj.rasterizer import BatchContext  # noqa: E402
 
 def main():
     K = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    wl = sys.argv[2] if len(sys.argv) > 2 else "cfg2"
     lib = _lib.load()
     dev = torch.device("cuda:0")
-    cam, sc = syn.config_scene("cfg2")
+    cam, sc = syn.config_scene(wl)
     cams = syn.keyframe_cameras(K, W=cam["W"], H=cam["H"], fx=cam["fx"], fy=cam["fy"], cx=cam["cx"], cy=cam["cy"])
     P, W, H, M = sc["means3D"].shape[0], cam["W"], cam["H"], sc["shs"].shape[1]
     t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)  # noqa: E731
     bc = BatchContext(K, P, W, H, M, dev)
-    kw = dict(shs=t(sc["shs"]), scales=t(sc["scales"]), rotations=t(sc["rotations"]), sh_degree=3)
+    kw = dict(shs=t(sc["shs"]), scales=t(sc["scales"]), rotations=t(sc["rotations"]), sh_degree=int(round(M ** 0.5)) - 1)
     views, projs, cps = (t(np.stack([c[k] for c in cams])) for k in ("viewmatrix", "projmatrix", "campos"))
     bg, means, opac, praw = torch.zeros(3, device=dev), t(sc["means3D"]), t(sc["opacities"]), t(cams[0]["projmatrix_raw"])
     rng = np.random.default_rng(0)
