@@ -87,12 +87,23 @@ class DeviceTracker:
         if w2c is not None:
             self.pose.reset(w2c)
 
+    def _sharded(self):
+        import torch.distributed as dist
+        return self.group is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+
     def _capture(self):
-        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ga):
-            self._render_and_grads(False)
-        with torch.cuda.graph(gb, pool=ga.pool()):
-            self._step()
+        ga = torch.cuda.CUDAGraph()
+        if self._sharded():  # the collective sits between two graphs
+            gb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga):
+                self._render_and_grads(False)
+            with torch.cuda.graph(gb, pool=ga.pool()):
+                self._step()
+        else:  # one process: the whole iteration is ONE graph (each graph launch has a cost of its own)
+            gb = None
+            with torch.cuda.graph(ga):
+                self._render_and_grads(False)
+                self._step()
         self._graphs = (ga, gb, self.ctx.binning.data_ptr())
 
     def _eager(self, sync):
@@ -116,8 +127,9 @@ class DeviceTracker:
                     if self._graphs is None or self._graphs[2] != self.ctx.binning.data_ptr():
                         self._capture()  # (again if the arena was re-allocated: the graph holds its address)
                     self._graphs[0].replay()
-                    tbs.allreduce_pose_terms(self.packed, self.group)
-                    self._graphs[1].replay()
+                    if self._graphs[1] is not None:
+                        tbs.allreduce_pose_terms(self.packed, self.group)
+                        self._graphs[1].replay()
                 done += 1
                 if check_every and done % check_every == 0 and bool(self.pose.converged.item() != 0.0):
                     break

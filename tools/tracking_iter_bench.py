@@ -106,7 +106,8 @@ def main():
     # D: the whole iteration on the device: render from the tracker's matrices -> loss seeds -> backward -> Adam + update_pose
     from gsaj import pose_step
     w2c = np.asarray(cam["viewmatrix"], np.float32).reshape(4, 4).T
-    pt = pose_step.PoseTracker(w2c, cam["projmatrix_raw"], dev)
+    # learning rates 0: the ground truth here is noise, a moving pose would drift off the scene and make later sections cheaper
+    pt = pose_step.PoseTracker(w2c, cam["projmatrix_raw"], dev, lr_rot=0.0, lr_trans=0.0, lr_exposure_a=0.0, lr_exposure_b=0.0)
     fd = dict(fa)
 
     def iter_d():
