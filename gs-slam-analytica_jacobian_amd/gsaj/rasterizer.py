@@ -452,6 +452,13 @@ class BatchContext:
         self.bin_stride = self.lib.gsaj_binning_workspace_bytes(self.capacity)
         self.binning = torch.empty(self.K * self.bin_stride, device=self.dev, dtype=torch.uint8)
 
+    def set_tile_band(self, tile_row_begin, tile_row_end, views=None):
+        """Render only tile rows [begin, end) of the given views (default: all K) from now on -- gsaj_set_tile_band on each view's
+        block of the image workspace.  (0, rows) restores whole frames."""
+        for v in (range(self.K) if views is None else views):
+            _lib.check(self.lib.gsaj_set_tile_band(self.W, self.H, self.img.data_ptr() + int(v) * self.img_stride, int(tile_row_begin),
+                                                   int(tile_row_end), _stream(self.dev)), "gsaj_set_tile_band")
+
     def status(self):
         """Blocking: per view (num_rendered, longest tile list, aborted)."""
         out, st = [], _stream(self.dev)

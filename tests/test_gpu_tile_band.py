@@ -177,6 +177,39 @@ def test_band_is_kept_until_changed_and_whole_frame_restores_bitwise():
     assert torch.equal(g["tau_sum"], gw["tau_sum"]) and torch.equal(g["mean3D"], gw["mean3D"])
 
 
+def test_band_on_a_batched_window_equals_banded_single_views():
+    """BatchContext.set_tile_band: the band lives in each view's block of the image workspace; the batched launches must give
+    each view the bits of a banded single-view frame."""
+    import torch
+    from gsaj.rasterizer import BatchContext, FrameContext
+
+    cam0, sc, deg = hp.make("p6000_640x480_sh1")
+    K = 3
+    cams = syn.keyframe_cameras(K, W=cam0["W"], H=cam0["H"], fx=cam0["fx"], fy=cam0["fy"], cx=cam0["cx"], cy=cam0["cy"])
+    dev, t, M, kw, a = _tensors(cam0, sc)
+    P, W, H = sc["means3D"].shape[0], cam0["W"], cam0["H"]
+    views, projs, cps = (t(np.stack([c[k] for c in cams])) for k in ("viewmatrix", "projmatrix", "campos"))
+    band = (9, 21)
+    bc = BatchContext(K, P, W, H, M, dev)
+    bc.set_tile_band(*band)
+    bc.forward(a["bg"], a["means"], a["opac"], views, projs, cps, cam0["tanfovx"], cam0["tanfovy"], sh_degree=deg, **kw)
+    seeds = [hp.seeds(cam0, seed=80 + k) for k in range(K)]
+    dLc, dLd = t(np.stack([s[0] for s in seeds])), t(np.stack([s[1] for s in seeds]))
+    g = bc.backward(a["bg"], a["means"], views, projs, a["praw"], cps, cam0["tanfovx"], cam0["tanfovy"], dLc, dLd, sh_degree=deg, **kw)
+    for k in range(K):
+        fc = FrameContext(P, W, H, M, dev)
+        fc.set_tile_band(*band)
+        fc.forward(a["bg"], a["means"], a["opac"], views[k], projs[k], cps[k], cam0["tanfovx"], cam0["tanfovy"], sh_degree=deg, **kw)
+        gs = fc.backward(a["bg"], a["means"], views[k], projs[k], a["praw"], cps[k], cam0["tanfovx"], cam0["tanfovy"], dLc[k], dLd[k],
+                         sh_degree=deg, **kw)
+        assert torch.equal(bc.color[k], fc.color) and torch.equal(bc.radii[k], fc.radii) and torch.equal(bc.n_touched[k], fc.n_touched)
+        assert float(bc.opacity[k][:, : band[0] * 16].abs().max()) == 0.0 and float(bc.opacity[k][:, band[1] * 16:].abs().max()) == 0.0
+        assert float((g["tau_all"][k] - gs["tau_sum"]).abs().max()) <= 3e-6 * float(gs["tau_sum"].abs().max())
+    bc.set_tile_band(0, tbs.tile_rows(H), views=[1])  # view 1 back to the whole frame, the others stay banded
+    bc.forward(a["bg"], a["means"], a["opac"], views, projs, cps, cam0["tanfovx"], cam0["tanfovy"], sh_degree=deg, **kw)
+    assert float(bc.opacity[1][:, : band[0] * 16].abs().max()) > 0.0 and float(bc.opacity[0][:, : band[0] * 16].abs().max()) == 0.0
+
+
 def test_uninitialised_image_workspace_is_not_mistaken_for_a_band():
     """The synchronous entry points do not ask for a zeroed image workspace (the drop-in binding hands over torch.empty
     memory): whatever bytes it holds, the whole frame is rendered."""
