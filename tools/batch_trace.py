@@ -54,6 +54,15 @@ def main():
         print("%-5s waves %6d span %6.1f us | life mean %5.1f p95 %5.1f max %5.1f | start p50 %5.1f p95 %5.1f max %5.1f | end p50 %5.1f p95 %5.1f p99 %5.1f | avg waves in flight %6.0f"
               % (name, len(s), (e.max() - t0) * 0.01, life.mean(), np.percentile(life, 95), life.max(), *np.percentile((s - t0) * 0.01, [50, 95, 100]),
                  *np.percentile((e - t0) * 0.01, [50, 95, 99]), busy))
+        if name in ("pre", "scat"):  # phase stamps (indexed by workgroup only: one view's, whichever wrote last)
+            nb = ((P + 255) // 256) * 4
+            raw = np.zeros((nb, 4), np.uint64)
+            fn(raw.ctypes.data, nb)
+            lo32 = np.uint64(0xffffffff)
+            ph = [raw[:, 2] >> np.uint64(32), raw[:, 2] & lo32, raw[:, 3] >> np.uint64(32), raw[:, 3] & lo32]
+            labels = {"pre": "per-Gaussian work / histogram flush + block scan / drain + ticket / frame scan (last workgroup)",
+                      "scat": "zero LDS + loads / LDS count / reserve (returning atomics) / stores"}[name]
+            print("      phases (us, mean): %s = %s" % (labels, " / ".join("%.1f" % (x.astype(np.int64).mean() * 0.01) for x in ph)))
 
 
 if __name__ == "__main__":
