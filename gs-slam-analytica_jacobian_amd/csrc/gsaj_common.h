@@ -331,6 +331,18 @@ __device__ __forceinline__ uint32_t gsaj_record_emission_slot(const float4 *__re
 }
 #endif
 
+#ifdef __HIPCC__
+// Four consecutive words written by OTHER workgroups of this launch (L2 atomics / write-through stores): one 16-byte load that
+// bypasses this CU's L1 and this XCD's L2 (sc0 sc1), with its wait inside the statement (the compiler takes an asm's outputs
+// for ready when the statement ends).  Coherent loads cost ~100 ns each and do not overlap (tools/chain_trace.py), so the
+// "last workgroup sums the partials" tails use as few and as wide ones as they can.
+__device__ __forceinline__ uint4 gsaj_coherent_load_x4(const void *src) {
+  uint4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(src) : "memory");
+  return v;
+}
+#endif
+
 // ---- optional per-wave schedule trace (build with -DGSAJ_BLOCK_TRACE; tools/block_trace.py) -----------------
 // Each traced kernel records, per wave: start and end of the 100 MHz wall clock, HW_ID and XCC_ID.
 #ifdef GSAJ_BLOCK_TRACE

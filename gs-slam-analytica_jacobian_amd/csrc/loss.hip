@@ -25,6 +25,7 @@ struct LossParams {
   uint32_t *ticket;   // zero between launches (reset by the last workgroup)
   const uint32_t *n_valid;  // COMPUTE_LOSS: number of pixels with gt_depth > 0 inside the mask (k_count_valid)
   float *out;         // [5]: loss, L_rgb, L_depth, dL/da, dL/db
+  size_t ws_stride;   // batched launch (gridDim.y = views): bytes between consecutive views' workspace blocks
 };
 
 __device__ __forceinline__ float sgn(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
@@ -33,6 +34,21 @@ __global__ __launch_bounds__(LOSS_BLOCK) void k_loss_seeds(LossParams p) {
   __shared__ float red[4][LOSS_BLOCK / 64];
   __shared__ bool is_last;
   const size_t HW = (size_t)p.W * p.H;
+  if (blockIdx.y) {  // batched launch: view blockIdx.y of [K,3,H,W] / [K,1,H,W] / [K,H,W] / [K] arrays and K workspace blocks
+    const size_t v = blockIdx.y;
+    p.color += v * 3 * HW; p.gt_color += v * 3 * HW; p.dL_dcolor += v * 3 * HW;
+    p.opacity += v * HW; p.dL_ddepth += v * HW;
+    if (p.depth) p.depth += v * HW;
+    if (p.gt_depth) p.gt_depth += v * HW;
+    if (p.grad_mask) p.grad_mask += v * HW;
+    if (p.dL_dopacity) p.dL_dopacity += v * HW;
+    if (p.exp_a) p.exp_a += v;
+    if (p.exp_b) p.exp_b += v;
+    p.out += 5 * v;
+    p.partials = reinterpret_cast<float *>(reinterpret_cast<char *>(p.partials) + v * p.ws_stride);
+    p.ticket = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(p.ticket) + v * p.ws_stride);
+    p.n_valid = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(p.n_valid) + v * p.ws_stride);
+  }
   const bool tracking = p.flags & GSAJ_LOSS_TRACKING, mono = p.flags & GSAJ_LOSS_MONOCULAR, noexp = p.flags & GSAJ_LOSS_NO_EXPOSURE;
   // compute_loss of the verification harness (Jacobian_test.py:155-196): mask given per pixel, colour term = mean over
   // 3HW, depth term = mean over the valid pixels only, plain sum of the two (no alpha weighting, no exposure)
@@ -105,21 +121,12 @@ __global__ __launch_bounds__(LOSS_BLOCK) void k_loss_seeds(LossParams p) {
   if (!is_last) return;
   __shared__ double fin[4][LOSS_BLOCK / 64];
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
-  for (unsigned b0 = threadIdx.x; b0 < gridDim.x; b0 += 4 * LOSS_BLOCK) {  // unconditional loads, 16 in flight, masked afterwards
-    float t[4][4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const unsigned b = b0 + u * LOSS_BLOCK, bc = min(b, gridDim.x - 1);
-#pragma unroll
-      for (int c = 0; c < 4; c++) {
-        const float x = __hip_atomic_load(&p.partials[(size_t)bc * 4 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        t[u][c] = b < gridDim.x ? x : 0.f;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++)
-#pragma unroll
-      for (int c = 0; c < 4; c++) acc[c] += (double)t[u][c];
+  for (unsigned b = threadIdx.x; b < gridDim.x; b += LOSS_BLOCK) {  // a workgroup's four partials = one 16-byte coherent load
+    const uint4 u = gsaj_coherent_load_x4(p.partials + (size_t)b * 4);
+    acc[0] += (double)__uint_as_float(u.x);
+    acc[1] += (double)__uint_as_float(u.y);
+    acc[2] += (double)__uint_as_float(u.z);
+    acc[3] += (double)__uint_as_float(u.w);
   }
 #pragma unroll
   for (int c = 0; c < 4; c++) {
@@ -186,6 +193,7 @@ extern "C" int gsaj_loss_seeds(int W, int H, int flags, float alpha, float rgb_b
   p.partials = (float *)(base + 256);
   p.out = out_scalars;
   p.n_valid = (uint32_t *)(base + 64);
+  p.ws_stride = 0;
   if ((flags & GSAJ_LOSS_COMPUTE_LOSS) && !mono) {
     GSAJ_HIP_CHECK(hipMemsetAsync(base + 64, 0, sizeof(uint32_t), (hipStream_t)stream));
     hipLaunchKernelGGL(k_count_valid, dim3(64), dim3(LOSS_BLOCK), 0, (hipStream_t)stream, (size_t)W * H, gt_depth, grad_mask,
@@ -193,6 +201,35 @@ extern "C" int gsaj_loss_seeds(int W, int H, int flags, float alpha, float rgb_b
   }
   const unsigned nblk = (unsigned)(((size_t)W * H + LOSS_BLOCK * LOSS_PPT - 1) / (LOSS_BLOCK * LOSS_PPT));
   hipLaunchKernelGGL(k_loss_seeds, dim3(nblk), dim3(LOSS_BLOCK), 0, (hipStream_t)stream, p);
+  GSAJ_HIP_CHECK(hipGetLastError());
+  return GSAJ_OK;
+}
+
+extern "C" int gsaj_loss_seeds_batch(int K, int W, int H, int flags, float alpha, float rgb_boundary_threshold, const float *color,
+                                     const float *depth, const float *opacity, const float *gt_color, const float *gt_depth,
+                                     const uint8_t *grad_mask, const float *exposure_a, const float *exposure_b, float *dL_dcolor,
+                                     float *dL_ddepth, float *dL_dopacity, float *out_scalars, void *loss_ws, void *stream) {
+  const bool mono = flags & GSAJ_LOSS_MONOCULAR, noexp = flags & GSAJ_LOSS_NO_EXPOSURE;
+  if (K <= 0 || W <= 0 || H <= 0 || !color || !opacity || !gt_color || !dL_dcolor || !dL_ddepth || !out_scalars || !loss_ws ||
+      (!mono && (!depth || !gt_depth)) || (!noexp && (!exposure_a || !exposure_b)) || (flags & GSAJ_LOSS_COMPUTE_LOSS) ||
+      ((uintptr_t)loss_ws & 255)) {
+    gsaj_set_error("gsaj_loss_seeds_batch: invalid argument (K=%d W=%d H=%d flags=%d; the workspace must be 256-byte aligned; "
+                   "GSAJ_LOSS_COMPUTE_LOSS has no batched form)", K, W, H, flags);
+    return GSAJ_ERR_INVALID_ARGUMENT;
+  }
+  LossParams p;
+  p.W = W; p.H = H; p.flags = flags; p.alpha = alpha; p.rgb_thr = rgb_boundary_threshold;
+  p.color = color; p.depth = depth; p.opacity = opacity; p.gt_color = gt_color; p.gt_depth = gt_depth;
+  p.grad_mask = grad_mask; p.exp_a = exposure_a; p.exp_b = exposure_b;
+  p.dL_dcolor = dL_dcolor; p.dL_ddepth = dL_ddepth; p.dL_dopacity = dL_dopacity;
+  char *base = (char *)loss_ws;
+  p.ticket = (uint32_t *)base;
+  p.partials = (float *)(base + 256);
+  p.out = out_scalars;
+  p.n_valid = (uint32_t *)(base + 64);
+  p.ws_stride = (gsaj_loss_workspace_bytes(W, H) + 255) & ~(size_t)255;
+  const unsigned nblk = (unsigned)(((size_t)W * H + LOSS_BLOCK * LOSS_PPT - 1) / (LOSS_BLOCK * LOSS_PPT));
+  hipLaunchKernelGGL(k_loss_seeds, dim3(nblk, (unsigned)K), dim3(LOSS_BLOCK), 0, (hipStream_t)stream, p);
   GSAJ_HIP_CHECK(hipGetLastError());
   return GSAJ_OK;
 }

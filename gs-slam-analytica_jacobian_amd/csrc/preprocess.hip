@@ -323,15 +323,6 @@ __device__ uint32_t tail_exclusive_scan(const uint32_t *in, uint32_t *out, int n
   return total;
 }
 
-// Four consecutive words written by OTHER workgroups of this launch (L2 atomics / write-through stores): one 16-byte load that
-// bypasses this CU's L1 and this XCD's L2.  Coherent loads cost ~100 ns each and do not overlap (see gsaj_sum_partials in
-// gaussian_bwd.hip), so the tail code below uses as few and as wide ones as it can.
-__device__ __forceinline__ uint4 coherent_load_x4(const uint32_t *src) {
-  uint4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(src) : "memory");
-  return v;
-}
-
 // The per-tile histogram the other workgroups flushed -> (1) its exclusive scan (tile_offset), (2) the longest list, (3) the order
 // in which both compositors take their tiles: longest list first (64 length classes, counting sort in LDS).  A launch that
 // oversubscribes the chip (a batched window: 9600 tiles for 1280 workgroup slots) then ends on its short tiles instead of waiting
@@ -342,7 +333,7 @@ __device__ uint32_t tile_scan_and_schedule(int tiles, ImageWS im, uint32_t *len,
   __shared__ uint32_t wsum[PRE_BLOCK / 64], wmax[PRE_BLOCK / 64], cls[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int c = tid; 4 * c < tiles; c += PRE_BLOCK) {  // (reads up to 3 words past `tiles`: still inside the zeroed counter block)
-    const uint4 v = coherent_load_x4(im.tile_count + 4 * c);
+    const uint4 v = gsaj_coherent_load_x4(im.tile_count + 4 * c);
     len[4 * c] = v.x;
     if (4 * c + 1 < tiles) len[4 * c + 1] = v.y;
     if (4 * c + 2 < tiles) len[4 * c + 2] = v.z;

@@ -62,6 +62,7 @@ SIGNATURES = {
     "gsaj_isotropic_workspace_bytes": (c_size_t, [c_int]),
     "gsaj_isotropic_loss": (c_int, [c_int, c_int, c_float, P, P, c_int, P, P, P]),
     "gsaj_loss_seeds": (c_int, [c_int, c_int, c_int, c_float, c_float] + [P] * 8 + [P] * 4 + [P, P]),
+    "gsaj_loss_seeds_batch": (c_int, [c_int] + [c_int, c_int, c_int, c_float, c_float] + [P] * 8 + [P] * 4 + [P, P]),
 }
 
 _lib = None

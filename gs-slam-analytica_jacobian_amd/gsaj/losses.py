@@ -56,6 +56,48 @@ class LossSeeds:
                 "dL_dopacity": self.dL_dopacity if want_opacity_grad else None}
 
 
+class LossSeedsBatch:
+    """LossSeeds for the K views of a mapping window in one launch (C ABI gsaj_loss_seeds_batch): image / gt_image [K,3,H,W],
+    depth / opacity [K,1,H,W], gt_depth / grad_mask [K,H,W], exposure_a / exposure_b [K].  The seeds come out as
+    dL_dcolor [K,3,H,W] and dL_ddepth [K,1,H,W] -- what BatchContext.backward takes -- and scalars [K,5] = per keyframe
+    (loss, L_rgb, L_depth, dL/da, dL/db); the window's loss is scalars[:, 0].sum() (slam_backend.py:209-232)."""
+
+    def __init__(self, K, W, H, device):
+        self.lib = _lib.load()
+        self.K, self.W, self.H, self.dev = int(K), int(W), int(H), torch.device(device)
+        if self.dev.type != "cuda":
+            raise _lib.GsajError("LossSeedsBatch needs a HIP device (there is no CPU path)")
+        stride = (self.lib.gsaj_loss_workspace_bytes(self.W, self.H) + 255) & ~255
+        self.ws = torch.zeros(self.K * stride + 256, dtype=torch.uint8, device=self.dev)
+        self._ws_ptr = (self.ws.data_ptr() + 255) & ~255
+        f = dict(dtype=torch.float32, device=self.dev)
+        self.dL_dcolor = torch.empty((self.K, 3, self.H, self.W), **f)
+        self.dL_ddepth = torch.empty((self.K, 1, self.H, self.W), **f)
+        self.scalars = torch.zeros((self.K, 5), **f)
+
+    def __call__(self, flags, alpha, rgb_boundary_threshold, image, depth, opacity, gt_image, gt_depth=None, grad_mask=None,
+                 exposure_a=None, exposure_b=None):
+        K, H, W = self.K, self.H, self.W
+        want = {"image": (image, (K, 3, H, W)), "depth": (depth, (K, 1, H, W)), "opacity": (opacity, (K, 1, H, W)),
+                "gt_image": (gt_image, (K, 3, H, W)), "gt_depth": (gt_depth, (K, H, W)), "exposure_a": (exposure_a, (K,)),
+                "exposure_b": (exposure_b, (K,))}
+        for name, (x, shape) in want.items():
+            if x is None:
+                continue
+            if x.device.type != "cuda" or x.dtype != torch.float32 or not x.is_contiguous() or x.numel() != int(torch.tensor(shape).prod()):
+                raise _lib.GsajError("%s must be a contiguous float32 device tensor of shape %s" % (name, shape))
+        gm = None if grad_mask is None else grad_mask.to(device=self.dev, dtype=torch.uint8).contiguous().view(-1)
+        if gm is not None and gm.numel() != K * H * W:
+            raise _lib.GsajError("grad_mask must have K*H*W elements")
+        _lib.check(self.lib.gsaj_loss_seeds_batch(K, W, H, int(flags), float(alpha), float(rgb_boundary_threshold), _ptr(image), _ptr(depth),
+                                                  _ptr(opacity), _ptr(gt_image), _ptr(gt_depth), _ptr(gm), _ptr(exposure_a),
+                                                  _ptr(exposure_b), _ptr(self.dL_dcolor), _ptr(self.dL_ddepth), None, _ptr(self.scalars),
+                                                  self._ws_ptr, torch.cuda.current_stream(self.dev).cuda_stream), "gsaj_loss_seeds_batch")
+        return {"loss": self.scalars[:, 0], "l1_rgb": self.scalars[:, 1], "l1_depth": self.scalars[:, 2],
+                "dL_dexposure_a": self.scalars[:, 3], "dL_dexposure_b": self.scalars[:, 4], "dL_dcolor": self.dL_dcolor,
+                "dL_ddepth": self.dL_ddepth}
+
+
 def _cfg(config):
     tr = config["Training"]
     return bool(tr["monocular"]), float(tr["rgb_boundary_threshold"]), float(tr.get("alpha", 0.95))

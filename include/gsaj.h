@@ -267,6 +267,16 @@ int gsaj_loss_seeds(int W, int H, int flags, float alpha, float rgb_boundary_thr
                     const uint8_t *grad_mask, const float *exposure_a, const float *exposure_b, float *dL_dcolor,
                     float *dL_ddepth, float *dL_dopacity, float *out_scalars, void *loss_ws, void *stream);
 
+/* The same for the K views of a mapping window in ONE launch (utils/slam_backend.py:168-232 sums get_loss_mapping over the
+ * keyframes of the window): color / gt_color / dL_dcolor [K,3,H,W], depth / opacity / dL_ddepth / dL_dopacity [K,1,H,W], gt_depth /
+ * grad_mask [K,H,W], exposure_a / exposure_b [K] (one pair per keyframe, camera_utils.py:43-48), out_scalars [K,5]; view k gets
+ * exactly what gsaj_loss_seeds gives for its slices.  loss_ws: K blocks of gsaj_loss_workspace_bytes(W, H) rounded up to 256 bytes,
+ * 256-byte aligned, zeroed once.  GSAJ_LOSS_COMPUTE_LOSS has no batched form. */
+int gsaj_loss_seeds_batch(int K, int W, int H, int flags, float alpha, float rgb_boundary_threshold, const float *color,
+                          const float *depth, const float *opacity, const float *gt_color, const float *gt_depth,
+                          const uint8_t *grad_mask, const float *exposure_a, const float *exposure_b, float *dL_dcolor,
+                          float *dL_ddepth, float *dL_dopacity, float *out_scalars, void *loss_ws, void *stream);
+
 /* weight * mean |s_ij - mean_j(s_i.)| over scales [P,C] (C = 1..3) -> out_loss[0] (device), and its gradient into dL_dscales
  * [P,C] (may be NULL; accumulate != 0: added to what is there): the isotropic regulariser of compute_loss (weight 10,
  * Jacobian_test.py:169-171) and of the mapping loss (slam_backend.py:229-231).  iso_ws: gsaj_isotropic_workspace_bytes(P),

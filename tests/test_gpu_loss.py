@@ -69,3 +69,34 @@ def test_loss_seeds_full_frame_vs_oracle():
             assert bad.mean() <= 1e-5, bad.sum()
         np.testing.assert_allclose(float(o["dL_dexposure_a"]), r["dL_da"], rtol=1e-4, atol=1e-9)
         np.testing.assert_allclose(float(o["dL_dexposure_b"]), r["dL_db"], rtol=1e-4, atol=1e-9)
+
+
+@pytest.mark.parametrize("flags_name", ["mapping", "mapping_mono", "tracking", "mapping_init"])
+def test_batched_loss_seeds_equal_the_single_view_calls_bit_for_bit(flags_name):
+    """gsaj_loss_seeds_batch (the K keyframes of a mapping window in one launch, utils/slam_backend.py:168-232) gives every view
+    exactly what gsaj_loss_seeds gives for its slices -- seeds, loss terms, exposure gradients."""
+    import torch
+    from gsaj.losses import LossSeeds, LossSeedsBatch, MONOCULAR, NO_EXPOSURE, TRACKING
+
+    flags = {"mapping": 0, "mapping_mono": MONOCULAR, "tracking": TRACKING, "mapping_init": NO_EXPOSURE}[flags_name]
+    dev = torch.device("cuda:0")
+    K, W, H = 5, 100, 75
+    g = torch.Generator(device="cpu").manual_seed(7)
+    r = lambda *shape: torch.rand(*shape, generator=g).to(dev)  # noqa: E731
+    image, depth, opacity = r(K, 3, H, W), r(K, 1, H, W) * 3, r(K, 1, H, W)
+    gt_image, gt_depth = r(K, 3, H, W), (r(K, H, W) * 3) * (r(K, H, W) > 0.2)
+    mask = r(K, H, W) > 0.3
+    ea, eb = (r(K) - 0.5) * 0.2, (r(K) - 0.5) * 0.1
+    noexp = bool(flags & NO_EXPOSURE)
+    lb = LossSeedsBatch(K, W, H, dev)
+    for _ in range(2):  # twice: the tickets must have been reset
+        ob = lb(flags, 0.9, 0.01, image, depth, opacity, gt_image, None if flags & MONOCULAR else gt_depth, mask if flags & TRACKING else None,
+                None if noexp else ea, None if noexp else eb)
+    ls = LossSeeds(W, H, dev)
+    for k in range(K):
+        o = ls(flags, 0.9, 0.01, image[k], depth[k], opacity[k], gt_image[k], None if flags & MONOCULAR else gt_depth[k].contiguous(),
+               mask[k] if flags & TRACKING else None, None if noexp else ea[k:k + 1], None if noexp else eb[k:k + 1])
+        assert torch.equal(ob["dL_dcolor"][k], o["dL_dcolor"]) and torch.equal(ob["dL_ddepth"][k], o["dL_ddepth"])
+        assert torch.equal(lb.scalars[k], ls.scalars)
+    with pytest.raises(Exception, match="gsaj_loss_seeds_batch"):
+        lb(8, 0.9, 0.01, image, depth, opacity, gt_image, gt_depth)  # COMPUTE_LOSS has no batched form

@@ -69,7 +69,7 @@ def test_tracking_follows_the_camera_over_consecutive_frames():
 
 def test_mapping_window_lowers_its_loss_with_adam_on_the_bucket_gradients():
     import torch
-    from gsaj.losses import LossSeeds
+    from gsaj.losses import LossSeedsBatch
     from gsaj.rasterizer import BatchContext
 
     dev, t, cams, sc, g, bg, M, frames = _true_world()
@@ -88,8 +88,9 @@ def test_mapping_window_lowers_its_loss_with_adam_on_the_bucket_gradients():
     views, projs, cps = (t(np.stack([c[k] for c in cams])) for k in ("viewmatrix", "projmatrix", "campos"))
     praw = t(cams[0]["projmatrix_raw"])
     bc = BatchContext(K, P, W, H, M, dev)
-    ls = [LossSeeds(W, H, dev) for _ in range(K)]
-    dLc, dLd = torch.empty((K, 3, H, W), device=dev), torch.empty((K, 1, H, W), device=dev)
+    ls = LossSeedsBatch(K, W, H, dev)
+    gt_color, gt_depth = torch.stack([f[0] for f in frames]).contiguous(), torch.stack([f[1] for f in frames]).contiguous()
+    exp_a, exp_b = torch.zeros(K, device=dev), torch.zeros(K, device=dev)
     tx, ty = cams[0]["tanfovx"], cams[0]["tanfovy"]
     losses = []
     for it in range(40):
@@ -99,15 +100,10 @@ def test_mapping_window_lowers_its_loss_with_adam_on_the_bucket_gradients():
             rot = torch.nn.functional.normalize(params["rot"]).contiguous()
         geo = dict(sh_degree=3, shs=params["shs"].detach(), scales=scales, rotations=rot)
         bc.forward(bg, params["means3D"].detach(), opac, views, projs, cps, tx, ty, sync=(it == 0), **geo)
-        total = 0.0
-        for k in range(K):  # get_loss_mapping per keyframe (slam_utils.py:91-128): flags 0 = RGB-D mapping loss with exposure
-            o = ls[k](0, 0.95, 0.01, bc.color[k], bc.depth[k], bc.opacity[k], frames[k][0], frames[k][1], None,
-                      torch.zeros(1, device=dev), torch.zeros(1, device=dev))
-            dLc[k].copy_(o["dL_dcolor"])
-            dLd[k].copy_(o["dL_ddepth"])
-            total += float(o["loss"])
-        losses.append(total)
-        gr = bc.backward(bg, params["means3D"].detach(), views, projs, praw, cps, tx, ty, dLc, dLd, **geo)
+        # get_loss_mapping of every keyframe of the window in one launch (slam_utils.py:91-128; flags 0 = RGB-D mapping loss with exposure)
+        o = ls(0, 0.95, 0.01, bc.color, bc.depth, bc.opacity, gt_color, gt_depth, None, exp_a, exp_b)
+        losses.append(float(o["loss"].sum()))
+        gr = bc.backward(bg, params["means3D"].detach(), views, projs, praw, cps, tx, ty, o["dL_dcolor"], o["dL_ddepth"], **geo)
         with torch.no_grad():  # chain through the activations, then the optimiser takes the gradients as they come out of the bucket
             params["means3D"].grad = gr["mean3D"].clone()
             params["shs"].grad = gr["sh"].view_as(params["shs"]).clone()
