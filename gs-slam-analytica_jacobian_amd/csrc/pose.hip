@@ -27,6 +27,7 @@ struct PoseStepParams {
   float lr[8];
   float beta1, beta2, eps, threshold;
   float *st;
+  const uint8_t *active;  // batched launch: per-pose enable flags (NULL: all)
 };
 
 __device__ void so3_exp_and_v(const float *th, float R[9], float V[9]) {
@@ -53,8 +54,13 @@ __device__ void so3_exp_and_v(const float *th, float R[9], float V[9]) {
 }
 
 __global__ void k_pose_adam_step(PoseStepParams p) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  float *st = p.st;
+  if (threadIdx.x != 0) return;
+  // batched launch: workgroup k steps pose k ([K,6] gradients, [K,2] exposure gradients, K states); `active` (may be NULL) masks
+  // keyframes whose pose stays fixed (the reference skips uid 0, utils/slam_backend.py:255-258)
+  if (p.active && !p.active[blockIdx.x]) return;
+  p.g_tau += 6 * (size_t)blockIdx.x;
+  if (p.g_exp) p.g_exp += 2 * (size_t)blockIdx.x;
+  float *st = p.st + (size_t)GSAJ_POSE_STATE_FLOATS * blockIdx.x;
   const float t = st[PS_STEP] + 1.f;
   st[PS_STEP] = t;
   const float bc1 = 1.f - powf(p.beta1, t), bc2 = 1.f - powf(p.beta2, t);
@@ -129,7 +135,28 @@ extern "C" int gsaj_pose_adam_step(const float *dL_dtau, const float *dL_dexposu
   p.lr[6] = lr_exp_a; p.lr[7] = lr_exp_b;
   p.beta1 = beta1; p.beta2 = beta2; p.eps = eps; p.threshold = converged_threshold;
   p.st = pose_state;
+  p.active = nullptr;
   hipLaunchKernelGGL(k_pose_adam_step, dim3(1), dim3(64), 0, (hipStream_t)stream, p);
+  GSAJ_HIP_CHECK(hipGetLastError());
+  return GSAJ_OK;
+}
+
+extern "C" int gsaj_pose_adam_step_batch(int K, const float *dL_dtau, const float *dL_dexposure, const uint8_t *active, float lr_rot,
+                                         float lr_trans, float lr_exp_a, float lr_exp_b, float beta1, float beta2, float eps,
+                                         float converged_threshold, const float *projection_matrix, float *pose_states,
+                                         void *stream) {
+  if (K <= 0 || !dL_dtau || !pose_states) {
+    gsaj_set_error("gsaj_pose_adam_step_batch: K > 0, dL_dtau and pose_states are required");
+    return GSAJ_ERR_INVALID_ARGUMENT;
+  }
+  PoseStepParams p;
+  p.g_tau = dL_dtau; p.g_exp = dL_dexposure; p.projection = projection_matrix;
+  for (int i = 0; i < 3; i++) { p.lr[i] = lr_trans; p.lr[3 + i] = lr_rot; }
+  p.lr[6] = lr_exp_a; p.lr[7] = lr_exp_b;
+  p.beta1 = beta1; p.beta2 = beta2; p.eps = eps; p.threshold = converged_threshold;
+  p.st = pose_states;
+  p.active = active;
+  hipLaunchKernelGGL(k_pose_adam_step, dim3((unsigned)K), dim3(64), 0, (hipStream_t)stream, p);
   GSAJ_HIP_CHECK(hipGetLastError());
   return GSAJ_OK;
 }

@@ -57,6 +57,7 @@ SIGNATURES = {
     "gsaj_dist2": (c_int, [c_int, P, P, P, P]),
     "gsaj_pose_state_floats": (c_int, []),
     "gsaj_pose_adam_step": (c_int, [P, P] + [c_float] * 8 + [P, P, P]),
+    "gsaj_pose_adam_step_batch": (c_int, [c_int, P, P, P] + [c_float] * 8 + [P, P, P]),
     "gsaj_loss_workspace_bytes": (c_size_t, [c_int, c_int]),
     "gsaj_densification_stats": (c_int, [c_int, c_int] + [P] * 7 + [P]),
     "gsaj_isotropic_workspace_bytes": (c_size_t, [c_int]),

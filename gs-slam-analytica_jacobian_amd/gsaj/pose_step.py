@@ -64,3 +64,44 @@ class PoseTracker:
                                                 self.lr[0], self.lr[1], self.lr[2], self.lr[3], self.betas[0], self.betas[1], self.eps,
                                                 self.thr, self.projection.data_ptr(), self.state.data_ptr(), st),
                    "gsaj_pose_adam_step")
+
+
+class PoseTrackerBatch:
+    """K poses stepped in one launch (C ABI gsaj_pose_adam_step_batch): the keyframe poses of a mapping window, each with its own
+    Adam state (utils/slam_backend.py:255-262 steps the keyframe optimiser and calls update_pose per keyframe).  `state` is
+    [K, 80]; the matrices the next batched render needs come out as [K,4,4] / [K,3] views of it gathered by `matrices()`."""
+
+    def __init__(self, w2cs, projection_matrix, device, lr_rot=0.003, lr_trans=0.001, lr_exposure_a=0.01, lr_exposure_b=0.01,
+                 betas=(0.9, 0.999), eps=1e-8, converged_threshold=1e-4):
+        self.lib = _lib.load()
+        self.dev = torch.device(device)
+        if self.dev.type != "cuda":
+            raise _lib.GsajError("PoseTrackerBatch needs a HIP device (there is no CPU path)")
+        self.singles = [PoseTracker(w, projection_matrix, device, lr_rot, lr_trans, lr_exposure_a, lr_exposure_b, betas, eps,
+                                    converged_threshold) for w in w2cs]  # (initialises every state exactly as the single tracker does)
+        self.K = len(self.singles)
+        self.state = torch.stack([s.state for s in self.singles]).contiguous()
+        self.projection = self.singles[0].projection
+        self.lr, self.betas, self.eps, self.thr = self.singles[0].lr, self.singles[0].betas, self.singles[0].eps, self.singles[0].thr
+        del self.singles
+
+    def step(self, dL_dtau, dL_dexposure=None, active=None):
+        """dL_dtau [K,6] (BatchContext's g["tau_all"]), dL_dexposure [K,2] or None, active: [K] bool / uint8 or None."""
+        for t, shape in ((dL_dtau, (self.K, 6)), (dL_dexposure, (self.K, 2))):
+            if t is not None and (t.device.type != "cuda" or t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != shape):
+                raise _lib.GsajError("gradients must be contiguous float32 device tensors of shape [K,6] / [K,2]")
+        act = None if active is None else active.to(device=self.dev, dtype=torch.uint8).contiguous()
+        _lib.check(self.lib.gsaj_pose_adam_step_batch(self.K, dL_dtau.data_ptr(), None if dL_dexposure is None else dL_dexposure.data_ptr(),
+                                                      None if act is None else act.data_ptr(), self.lr[0], self.lr[1], self.lr[2],
+                                                      self.lr[3], self.betas[0], self.betas[1], self.eps, self.thr,
+                                                      self.projection.data_ptr(), self.state.data_ptr(),
+                                                      torch.cuda.current_stream(self.dev).cuda_stream), "gsaj_pose_adam_step_batch")
+
+    def matrices(self):
+        """(viewmatrices [K,4,4], projmatrices [K,4,4], campos [K,3]) as contiguous tensors for BatchContext.forward / backward."""
+        s = self.state
+        return s[:, 35:51].reshape(self.K, 4, 4).contiguous(), s[:, 51:67].reshape(self.K, 4, 4).contiguous(), s[:, 67:70].contiguous()
+
+    w2c = property(lambda s: s.state[:, 0:16].view(s.K, 4, 4))
+    exposure = property(lambda s: s.state[:, 33:35])
+    converged = property(lambda s: s.state[:, 77])

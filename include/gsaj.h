@@ -314,6 +314,14 @@ int gsaj_pose_adam_step(const float *dL_dtau, const float *dL_dexposure, float l
                         float lr_exp_b, float beta1, float beta2, float eps, float converged_threshold,
                         const float *projection_matrix, float *pose_state, void *stream);
 
+/* The same step for K poses in one launch (the keyframe poses of a mapping window, each with its own Adam state:
+ * utils/slam_backend.py:255-262 steps the keyframe optimiser and calls update_pose per keyframe, skipping uid 0):
+ * dL_dtau [K,6] (the dL_dtau_sum rows of gsaj_rasterize_backward_batch), dL_dexposure [K,2] or NULL, active [K] bytes or NULL
+ * (0: the pose and its Adam state are left untouched), pose_states [K, GSAJ_POSE_STATE_FLOATS]; the learning rates are shared. */
+int gsaj_pose_adam_step_batch(int K, const float *dL_dtau, const float *dL_dexposure, const uint8_t *active, float lr_rot,
+                              float lr_trans, float lr_exp_a, float lr_exp_b, float beta1, float beta2, float eps,
+                              float converged_threshold, const float *projection_matrix, float *pose_states, void *stream);
+
 /* ---- distCUDA2 -------------------------------------------------------------------
  * simple_knn._C.distCUDA2 (reference submodules/simple-knn/simple_knn.cu:45-220, spatial.cu): for P points
  * [P,3] the mean of the squared distances to the 3 nearest other points -> mean_dists [P].  Exact search;
