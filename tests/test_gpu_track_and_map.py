@@ -116,3 +116,44 @@ def test_mapping_window_lowers_its_loss_with_adam_on_the_bucket_gradients():
     assert bc.status()[0][2] is False
     assert losses[-1] < 0.6 * losses[0], (losses[0], losses[-1])
     assert all(b < a * 1.05 for a, b in zip(losses, losses[1:])), "the window loss should go down almost monotonically"
+
+
+def test_window_pose_refinement_with_the_batched_pose_step():
+    """Keyframe poses of the window optimised on a fixed map, everything batched: BatchContext -> LossSeedsBatch ->
+    backward -> PoseTrackerBatch.step on the K rows of dL/dtau (keyframe 0 stays fixed, as in slam_backend.py:255-258)."""
+    import torch
+    from gsaj.losses import LossSeedsBatch
+    from gsaj.pose_step import PoseTrackerBatch
+    from gsaj.rasterizer import BatchContext
+
+    dev, t, cams, sc, g, bg, M, frames = _true_world()
+    P, K = g["means3D"].shape[0], len(cams)
+    rng = np.random.default_rng(9)
+    w2c_true = [np.ascontiguousarray(c["viewmatrix"].T).astype(np.float32) for c in cams]
+    w2c0 = [w.copy() for w in w2c_true]
+    for k in range(1, K):
+        w2c0[k][:3, 3] += rng.normal(scale=0.01, size=3).astype(np.float32)
+    poses = PoseTrackerBatch(w2c0, t(cams[0]["projmatrix_raw"]), dev, lr_rot=0.001, lr_trans=0.001, lr_exposure_a=0.0, lr_exposure_b=0.0)
+    active = torch.tensor([0] + [1] * (K - 1), dtype=torch.uint8, device=dev)
+    bc = BatchContext(K, P, W, H, M, dev)
+    ls = LossSeedsBatch(K, W, H, dev)
+    gt_color, gt_depth = torch.stack([f[0] for f in frames]).contiguous(), torch.stack([f[1] for f in frames]).contiguous()
+    geo = dict(sh_degree=3, shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
+    praw = t(cams[0]["projmatrix_raw"])
+    tx, ty = cams[0]["tanfovx"], cams[0]["tanfovy"]
+    err0 = [float(np.abs(w2c0[k][:3, 3] - w2c_true[k][:3, 3]).max()) for k in range(K)]
+    first = None
+    for it in range(120):
+        views, projs, cps = poses.matrices()
+        bc.forward(bg, g["means3D"], g["opacities"], views, projs, cps, tx, ty, sync=(it == 0), **geo)
+        o = ls(0, 0.9, 0.01, bc.color, bc.depth, bc.opacity, gt_color, gt_depth, None, poses.exposure[:, 0].contiguous(),
+               poses.exposure[:, 1].contiguous())
+        first = float(o["loss"].sum()) if first is None else first
+        gr = bc.backward(bg, g["means3D"], views, projs, praw, cps, tx, ty, o["dL_dcolor"], o["dL_ddepth"], **geo)
+        poses.step(gr["tau_all"].contiguous(), ls.scalars[:, 3:5].contiguous(), active)
+    est = poses.w2c.cpu().numpy()
+    assert np.array_equal(est[0], w2c_true[0])  # the fixed keyframe did not move
+    for k in range(1, K):
+        err = float(np.abs(est[k][:3, 3] - w2c_true[k][:3, 3]).max())
+        assert err < 0.4 * err0[k], (k, err0[k], err)
+    assert float(o["loss"].sum()) < 0.5 * first
