@@ -76,6 +76,32 @@ class GaussianModel:
     def parameters(self):
         return [self._xyz, self._features_dc, self._features_rest, self._opacity, self._scaling, self._rotation]
 
+    def assign_bucket_gradients(self, g, accumulate=False):
+        """.grad of the six raw parameters from the gradients a batched backward leaves in its bucket (gsaj.rasterizer.BatchContext /
+        FrameContext: g["mean3D"], g["sh"], g["opacity"], g["scale"], g["rot"] w.r.t. the ACTIVATED quantities the rasteriser is fed):
+        what loss.backward() would have left there through the activations of the reference model (exp, normalize, sigmoid, cat;
+        gaussian_model.py:41-56, 141-165), in closed form.  accumulate=True adds to existing .grad (several windows per step)."""
+        with torch.no_grad():
+            P = self._xyz.shape[0]
+            sh = g["sh"].view(P, -1, 3)
+            op = self.get_opacity
+            sc = self.get_scaling
+            g_sc = g["scale"] * (sc if sc.shape[1] == 3 else sc.expand(-1, 3))
+            if self._scaling.shape[1] == 1:  # isotropic model: one log-scale drives the three axes (gaussian_renderer/__init__.py:98-101)
+                g_sc = g_sc.sum(dim=1, keepdim=True)
+            q = self._rotation
+            n = q.norm(dim=1, keepdim=True).clamp_min(1e-12)
+            qh = q / n
+            g_q = (g["rot"] - qh * (g["rot"] * qh).sum(dim=1, keepdim=True)) / n
+            grads = ((self._xyz, g["mean3D"]), (self._features_dc, sh[:, :1, :]), (self._features_rest, sh[:, 1:, :]),
+                     (self._opacity, g["opacity"].view(P, 1) * op * (1.0 - op)), (self._scaling, g_sc), (self._rotation, g_q))
+            for prm, gr in grads:
+                gr = gr.reshape(prm.shape).to(prm.dtype)
+                if accumulate and prm.grad is not None:
+                    prm.grad += gr
+                else:
+                    prm.grad = gr.clone()
+
     # ---- bookkeeping tensors + parameter I/O (SURVEY 8f-4) -----------------------------------------------------------
     def _init_aux(self):
         """The auxiliary tensors load_tensors / load_ply create (gaussian_model.py:124-131, 538-542)."""

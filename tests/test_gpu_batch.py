@@ -158,3 +158,56 @@ def test_batch_aborted_view_contributes_nothing_and_is_reported():
             assert torch.equal(b2.color[k], singles[k][0].color)
         else:
             assert float(g2["tau_all"][k].abs().max()) == 0.0
+
+
+def test_bucket_gradients_through_the_activations_equal_autograd_on_the_drop_in():
+    """GaussianModel.assign_bucket_gradients: the batched backward's bucket (gradients w.r.t. the ACTIVATED scales / rotations /
+    opacities / SH the rasteriser is fed) chained in closed form through the reference model's activations must leave in .grad of
+    the six RAW parameters what loss.backward() leaves there when the same K views go one by one through the drop-in
+    render() under torch autograd (slam_backend.py:168-232 does the latter)."""
+    import torch
+    from gaussian_splatting.gaussian_renderer import render
+    from gaussian_splatting.scene.gaussian_model import GaussianModel
+    from gsaj.rasterizer import BatchContext
+    from utils.camera_utils import Camera
+
+    dev = torch.device("cuda:0")
+    cam0, sc, deg = hp.make("p2000_160x120")
+    K = 3
+    cams = syn.keyframe_cameras(K, radius=0.2, W=cam0["W"], H=cam0["H"], fx=cam0["fx"], fy=cam0["fy"], cx=cam0["cx"], cy=cam0["cy"])
+    model = GaussianModel.from_activated(sc["means3D"], sc["scales"], 1.7 * sc["rotations"], sc["opacities"], sc["shs"], sh_degree=3, device=dev)
+    P, W, H, M = sc["means3D"].shape[0], cam0["W"], cam0["H"], sc["shs"].shape[1]
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)  # noqa: E731
+    bg = t(np.array([0.1, 0.2, 0.3]))
+    seeds = [hp.seeds(c, seed=60 + k) for k, c in enumerate(cams)]
+    dLc, dLd = t(np.stack([s[0] for s in seeds])), t(np.stack([s[1] for s in seeds]))
+
+    class Pipe:
+        convert_SHs_python = False
+        compute_cov3D_python = False
+
+    # (a) the drop-in, view by view, one backward over the summed "loss" = sum_k <seed_k, render_k>
+    for prm in model.parameters():
+        prm.grad = None
+    total = 0.0
+    for k, c in enumerate(cams):
+        pkg = render(Camera.from_synthetic(c, device=dev), model, Pipe, bg)
+        total = total + (pkg["render"] * dLc[k]).sum() + (pkg["depth"] * dLd[k]).sum()
+    total.backward()
+    want = [prm.grad.clone() for prm in model.parameters()]
+    # (b) the batched entry points + the closed-form chain
+    views, projs, cps = (t(np.stack([c[k] for c in cams])) for k in ("viewmatrix", "projmatrix", "campos"))
+    bc = BatchContext(K, P, W, H, M, dev)
+    with torch.no_grad():
+        geo = dict(sh_degree=3, shs=model.get_features.contiguous(), scales=model.get_scaling.contiguous(), rotations=model.get_rotation.contiguous())
+        xyz, op = model.get_xyz.detach().contiguous(), model.get_opacity.contiguous()
+    bc.forward(bg, xyz, op, views, projs, cps, cam0["tanfovx"], cam0["tanfovy"], **geo)
+    g = bc.backward(bg, xyz, views, projs, t(cams[0]["projmatrix_raw"]), cps, cam0["tanfovx"], cam0["tanfovy"], dLc, dLd, **geo)
+    model.assign_bucket_gradients(g)
+    names = ["_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"]
+    for nm, prm, w in zip(names, model.parameters(), want):
+        e = float((prm.grad - w).abs().max() / w.abs().max())
+        assert e < 2e-5, (nm, e)  # K = 3 views summed in the kernel vs three autograd accumulations: fp32 rounding
+    # accumulate=True: a second window adds up
+    model.assign_bucket_gradients(g, accumulate=True)
+    assert float((model._xyz.grad - 2 * want[0]).abs().max() / want[0].abs().max()) < 4e-5
