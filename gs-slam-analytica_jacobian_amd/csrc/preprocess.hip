@@ -584,7 +584,7 @@ __global__ __launch_bounds__(256) void k_tile_sort_records(int gx, int gy, const
                                                            const float *__restrict__ features, GeomWS g, ImageWS im,
                                                            const uint64_t *__restrict__ inst_key,
                                                            uint32_t *__restrict__ point_list,
-                                                           float4 *__restrict__ records, int cap, int rec16, ViewStrides vs) {
+                                                           float4 *__restrict__ records, int cap, int pass, int rec16, ViewStrides vs) {
   {
     const size_t view = blockIdx.y;
     g = geom_view(g, view * vs.geom);
@@ -604,15 +604,23 @@ __global__ __launch_bounds__(256) void k_tile_sort_records(int gx, int gy, const
   const int tid = threadIdx.x, tile = blockIdx.x;
   const uint32_t beg = im.tile_offset[tile * TILE_REP], end = im.tile_offset[(tile + 1) * TILE_REP];
   const int n = (int)(end - beg);
-  if (tid == 0) im.ranges[tile] = n > 0 ? make_uint2(beg, end) : make_uint2(0u, 0u);
-  if (tid == 0 && tile == 0) im.counters[7] = (uint32_t)rec16;  // record format of this frame (read by the compositors)
-  if (n > cap) {  // cannot happen with the max_tile_list of gsaj_forward_num_rendered / a frame_scan-checked capacity
-    if (tid == 0) atomicOr(&im.counters[1], ERR_TILE_LIST);
-    return;
+  // pass 0: the only launch.  Long lists (cap >= 4096 keys = 32 KB of LDS, where LDS and not wave slots bounds the resident
+  // workgroups) are sorted in TWO launches instead: pass 1 has LDS for `cap` keys and takes the tiles whose padded length exceeds
+  // cap / 2 (+ the bookkeeping of every tile), pass 2 has half the LDS -- twice the resident workgroups -- and takes the rest.
+  // At cfg5 (lists of ~3300, a few above 4096) one launch ran at 2 workgroups per CU: 4.2 of the window's 10.5 ms.
+  if (pass != 2) {
+    if (tid == 0) im.ranges[tile] = n > 0 ? make_uint2(beg, end) : make_uint2(0u, 0u);
+    if (tid == 0 && tile == 0) im.counters[7] = (uint32_t)rec16;  // record format of this frame (read by the compositors)
+    if (n > cap) {  // cannot happen with the max_tile_list of gsaj_forward_num_rendered / a frame_scan-checked capacity
+      if (tid == 0) atomicOr(&im.counters[1], ERR_TILE_LIST);
+      return;
+    }
   }
   if (n == 0) return;
   int m = 2;
   while (m < n) m <<= 1;
+  if (pass == 1 && 2 * m <= cap) return;  // pass 2's
+  if (pass == 2 && m > cap) return;       // pass 1's (here cap = half of pass 1's)
   for (int i = tid; i < m; i += 256) keys[i] = i < n ? inst_key[beg + i] : ~0ull;
   __syncthreads();
 #ifdef GSAJ_BLOCK_TRACE
@@ -770,8 +778,15 @@ int launch_tile_binning(int P, int R, int sort_cap, int rec16, int grid_x, int g
     if (sizeof(uint64_t) * (size_t)cap > 65536)  // lists of 8193 .. 16384 keys: more dynamic LDS than the 64 KB default limit
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_sort_records), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(sizeof(uint64_t) * (size_t)cap));
-    hipLaunchKernelGGL(k_tile_sort_records, dim3(grid_x * grid_y, views), dim3(256), sizeof(uint64_t) * (size_t)cap, s, grid_x, grid_y,
-                       radii, features, g, im, b.keys_unsorted, b.point_list, b.records, cap, rec16, vs);
+    if (cap >= 4096) {
+      hipLaunchKernelGGL(k_tile_sort_records, dim3(grid_x * grid_y, views), dim3(256), sizeof(uint64_t) * (size_t)cap, s, grid_x, grid_y,
+                         radii, features, g, im, b.keys_unsorted, b.point_list, b.records, cap, 1, rec16, vs);
+      hipLaunchKernelGGL(k_tile_sort_records, dim3(grid_x * grid_y, views), dim3(256), sizeof(uint64_t) * (size_t)(cap / 2), s, grid_x,
+                         grid_y, radii, features, g, im, b.keys_unsorted, b.point_list, b.records, cap / 2, 2, rec16, vs);
+    } else {
+      hipLaunchKernelGGL(k_tile_sort_records, dim3(grid_x * grid_y, views), dim3(256), sizeof(uint64_t) * (size_t)cap, s, grid_x, grid_y,
+                         radii, features, g, im, b.keys_unsorted, b.point_list, b.records, cap, 0, rec16, vs);
+    }
   }
   GSAJ_HIP_CHECK(hipGetLastError());
   return GSAJ_OK;
