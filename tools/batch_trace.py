@@ -54,6 +54,8 @@ def main():
         print("%-5s waves %6d span %6.1f us | life mean %5.1f p95 %5.1f max %5.1f | start p50 %5.1f p95 %5.1f max %5.1f | end p50 %5.1f p95 %5.1f p99 %5.1f | avg waves in flight %6.0f"
               % (name, len(s), (e.max() - t0) * 0.01, life.mean(), np.percentile(life, 95), life.max(), *np.percentile((s - t0) * 0.01, [50, 95, 100]),
                  *np.percentile((e - t0) * 0.01, [50, 95, 99]), busy))
+        first = int(((s - t0) * 0.01 < 3.0).sum())
+        print("      resident at once (waves started within the first 3 us): %d" % first)
         if name in ("pre", "scat"):  # phase stamps (indexed by workgroup only: one view's, whichever wrote last)
             nb = ((P + 255) // 256) * 4
             raw = np.zeros((nb, 4), np.uint64)
