@@ -44,7 +44,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"])
     ap.add_argument("--views", type=int, default=8, help="keyframes per mapping window (per rank), each with its own camera")
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
@@ -140,7 +140,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    a.warmup = max(a.warmup, 2)
+    # at least 10 untimed windows (~10 ms): the first window sizes the arenas synchronously, the second is the first asynchronous one,
+    # and a fresh box has been seen to spend tens of ms in its first launches (a 5-step run once timed at 10.9 ms per step)
+    a.warmup = max(a.warmup, 10)
     for _ in range(a.warmup):
         step()
     fence()
