@@ -17,12 +17,6 @@ void gsaj_set_error(const char *fmt, ...) {
   va_end(ap);
 }
 
-static uint32_t higher_msb(uint32_t n) {  // number of bits needed for tile ids (rasterizer_impl.cu:35-50)
-  uint32_t bits = 0;
-  while ((n >> bits) != 0 && bits < 32) bits++;
-  return bits;
-}
-
 // ---- event-based per-stage profiler ------------------------------------------------------------
 // Shared by every thread / stream of the process: the record table is guarded by a mutex, a record is claimed with an
 // atomic index, and the record a launch scope has open is thread-local (a scope opens and closes on one thread), so
@@ -105,7 +99,7 @@ int gsaj_version(void) { return 100; }
 size_t gsaj_geom_workspace_bytes(int P) { return geom_carve(nullptr, (size_t)(P > 0 ? P : 0), nullptr) + 256; }
 size_t gsaj_image_workspace_bytes(int W, int H) { return image_carve(nullptr, W, H, nullptr) + 256; }
 size_t gsaj_binning_workspace_bytes(int R) {
-  return bin_carve(nullptr, (size_t)(R > 0 ? R : 0), gsaj_sort_temp_bytes(R), nullptr) + 256;
+  return bin_carve(nullptr, (size_t)(R > 0 ? R : 0), nullptr) + 256;
 }
 
 static char *align_base(void *p) { return reinterpret_cast<char *>(gsaj_align(reinterpret_cast<size_t>(p))); }
@@ -185,10 +179,8 @@ int gsaj_forward_num_rendered(int W, int H, const void *image_ws, void *stream, 
     gsaj_set_error("internal error: tile histogram total != instance total");
     return GSAJ_ERR_HIP;
   }
-  if (host[1] & (ERR_CAPACITY | ERR_TILE_LIST)) {
-    gsaj_set_error("async forward aborted: %s (R=%u, longest tile list=%u)",
-                   (host[1] & ERR_CAPACITY) ? "binning arena too small" : "a tile list exceeds the LDS sort capacity", host[0],
-                   host[2]);
+  if (host[1] & ERR_CAPACITY) {
+    gsaj_set_error("async forward aborted: binning arena too small (R=%u, longest tile list=%u)", host[0], host[2]);
     return GSAJ_ERR_WORKSPACE_TOO_SMALL;
   }
   return GSAJ_OK;
@@ -252,22 +244,16 @@ int gsaj_forward_render(int P, int R, int max_tile_list, int W, int H, const flo
   ImageWS im;
   image_carve(align_base(image_ws), W, H, &im);
   BinWS b;
-  bin_carve(align_base(binning_ws), (size_t)R, gsaj_sort_temp_bytes(R), &b);
+  bin_carve(align_base(binning_ws), (size_t)R, &b);
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-  const int *rad = radii ? radii : g.internal_radii;
-  const float *features = colors_precomp ? colors_precomp : g.rgb;
+  (void)colors_precomp;  // (already in the splat rows: gsaj_forward_preprocess)
+  (void)radii;
+  // per-tile lists sorted by the tile's workgroup: in one LDS pass when the list fits the capacity sized from max_tile_list,
+  // in LDS-sized chunks + merge passes when it does not (max_tile_list < 0 forces that path with the smallest capacity)
+  const int sort_cap = max_tile_list < 0 ? 128 : (max_tile_list > SORT_CAP ? SORT_CAP : max_tile_list);
   int rc;
-  if (max_tile_list >= 0 && max_tile_list <= SORT_CAP) {
-    // fast path: per-tile lists sorted in LDS
-    if ((rc = launch_tile_binning(P, R, max_tile_list, (flags & GSAJ_FWD_RECORDS_FP16) ? 1 : 0, gx, gy, rad, features, g, b, im, 1, ViewStrides{0, 0, 0}, s)) != GSAJ_OK) return rc;
-  } else {
-    // a tile list exceeds the LDS sort capacity (or the caller forces it with max_tile_list < 0):
-    // global radix sort of (tile << 32 | depth) keys, as the reference does
-    if ((rc = launch_emit_keys(P, gx, gy, rad, g, b, im, s)) != GSAJ_OK) return rc;
-    if ((rc = launch_sort(R, 32 + (int)higher_msb((uint32_t)(gx * gy)), b, s)) != GSAJ_OK) return rc;
-    if ((rc = launch_ranges_and_records(P, R, gx, gy, rad, features, g, b, im, s)) != GSAJ_OK) return rc;
-  }
-  return launch_render_forward(P, W, H, gx, gy, bg, b, im, out_color, out_depth, out_opacity, n_touched, 1, ViewStrides{0, 0, 0}, s);
+  if ((rc = launch_tile_binning(P, sort_cap, (flags & GSAJ_FWD_RECORDS_FP16) ? 1 : 0, gx, gy, g, b, im, 1, ViewStrides{0, 0, 0}, s)) != GSAJ_OK) return rc;
+  return launch_render_forward(P, W, H, gx, gy, bg, g, b, im, out_color, out_depth, out_opacity, n_touched, 1, ViewStrides{0, 0, 0}, s);
 }
 
 int gsaj_rasterize_forward(int P, int D, int M, const float *bg, int W, int H, const float *means3D, const float *shs,
@@ -318,13 +304,11 @@ int gsaj_rasterize_forward_async(int P, int D, int M, const float *bg, int W, in
   ImageWS im;
   image_carve(align_base(image_ws), W, H, &im);
   BinWS b;
-  bin_carve(align_base(binning_ws), (size_t)capacity, gsaj_sort_temp_bytes(capacity), &b);
+  bin_carve(align_base(binning_ws), (size_t)capacity, &b);
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-  const int *rad = radii ? radii : g.internal_radii;
-  const float *features = colors_precomp ? colors_precomp : g.rgb;
   const int sort_cap = (tile_list_capacity > 0 && tile_list_capacity < SORT_CAP) ? tile_list_capacity : SORT_CAP;
-  if ((rc = launch_tile_binning(P, capacity, sort_cap, (flags & GSAJ_FWD_RECORDS_FP16) ? 1 : 0, gx, gy, rad, features, g, b, im, 1, ViewStrides{0, 0, 0}, s)) != GSAJ_OK) return rc;
-  return launch_render_forward(P, W, H, gx, gy, bg, b, im, out_color, out_depth, out_opacity, n_touched, 1, ViewStrides{0, 0, 0}, s);
+  if ((rc = launch_tile_binning(P, sort_cap, (flags & GSAJ_FWD_RECORDS_FP16) ? 1 : 0, gx, gy, g, b, im, 1, ViewStrides{0, 0, 0}, s)) != GSAJ_OK) return rc;
+  return launch_render_forward(P, W, H, gx, gy, bg, g, b, im, out_color, out_depth, out_opacity, n_touched, 1, ViewStrides{0, 0, 0}, s);
 }
 
 // ---- batched multi-view entry points: K views of ONE Gaussian map (a mapping window) --------------------------------
@@ -343,7 +327,7 @@ static int batch_workspaces(int K, int P, int capacity, int W, int H, void *geom
   }
   geom_carve(reinterpret_cast<char *>(geom_ws), (size_t)P, g);
   image_carve(reinterpret_cast<char *>(image_ws), W, H, im);
-  bin_carve(reinterpret_cast<char *>(binning_ws), (size_t)capacity, gsaj_sort_temp_bytes(capacity), b);
+  bin_carve(reinterpret_cast<char *>(binning_ws), (size_t)capacity, b);
   return GSAJ_OK;
 }
 
@@ -390,10 +374,9 @@ int gsaj_rasterize_forward_batch(int K, int P, int D, int M, const float *bg, in
   p.sort_cap = (tile_list_capacity > 0 && tile_list_capacity < SORT_CAP) ? tile_list_capacity : SORT_CAP;
   p.views = K;
   if ((rc = launch_preprocess(p, radii, n_touched, g, im, vs, s)) != GSAJ_OK) return rc;
-  if ((rc = launch_tile_binning(P, capacity, p.sort_cap, (flags & GSAJ_FWD_RECORDS_FP16) ? 1 : 0, p.grid_x, p.grid_y, radii, nullptr, g,
-                                b, im, K, vs, s)) != GSAJ_OK)
+  if ((rc = launch_tile_binning(P, p.sort_cap, (flags & GSAJ_FWD_RECORDS_FP16) ? 1 : 0, p.grid_x, p.grid_y, g, b, im, K, vs, s)) != GSAJ_OK)
     return rc;
-  return launch_render_forward(P, W, H, p.grid_x, p.grid_y, bg, b, im, out_color, out_depth, out_opacity, n_touched, K, vs, s);
+  return launch_render_forward(P, W, H, p.grid_x, p.grid_y, bg, g, b, im, out_color, out_depth, out_opacity, n_touched, K, vs, s);
 }
 
 int gsaj_rasterize_backward_batch(int K, int P, int D, int M, int capacity, const float *bg, int W, int H, const float *means3D,
@@ -422,7 +405,7 @@ int gsaj_rasterize_backward_batch(int K, int P, int D, int M, int capacity, cons
   hipStream_t s = (hipStream_t)stream;
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
   if (!(flags & GSAJ_BWD_ONLY_CHAIN)) {
-    if ((rc = launch_render_backward(capacity, W, H, gx, gy, bg, b, im, dL_dpix, dL_dpix_depth, K, vs, s)) != GSAJ_OK) return rc;
+    if ((rc = launch_render_backward(capacity, W, H, gx, gy, bg, g, b, im, dL_dpix, dL_dpix_depth, K, vs, s)) != GSAJ_OK) return rc;
     if ((rc = launch_gather_sums(P, K, radii, g, b, im, vs, s)) != GSAJ_OK) return rc;
   }
   if (flags & GSAJ_BWD_ONLY_COMPOSITE) return GSAJ_OK;
@@ -472,10 +455,10 @@ int gsaj_rasterize_backward(int P, int D, int M, int R, const float *bg, int W, 
   ImageWS im;
   image_carve(align_base(image_ws), W, H, &im);
   BinWS b;
-  bin_carve(align_base(binning_ws), (size_t)R, gsaj_sort_temp_bytes(R), &b);
+  bin_carve(align_base(binning_ws), (size_t)R, &b);
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
   // every output row is written by the kernels (zeros for culled Gaussians): no memsets
-  int rc = launch_render_backward(R, W, H, gx, gy, bg, b, im, dL_dpix, dL_dpix_depth, 1, ViewStrides{0, 0, 0}, s);
+  int rc = launch_render_backward(R, W, H, gx, gy, bg, g, b, im, dL_dpix, dL_dpix_depth, 1, ViewStrides{0, 0, 0}, s);
   if (rc != GSAJ_OK) return rc;
   BwdParams p;
   p.P = P; p.D = D; p.M = M; p.W = W; p.H = H;
@@ -526,7 +509,7 @@ int gsaj_debug_export(int P, int R, int W, int H, const void *geom_ws, const voi
   }
   if (binning_ws && R > 0) {
     BinWS b;
-    bin_carve(align_base(const_cast<void *>(binning_ws)), (size_t)R, gsaj_sort_temp_bytes(R), &b);
+    bin_carve(align_base(const_cast<void *>(binning_ws)), (size_t)R, &b);
     CP(point_list, b.point_list, sizeof(uint32_t) * (size_t)R);
   }
   if (image_ws) {

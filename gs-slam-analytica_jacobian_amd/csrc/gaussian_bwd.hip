@@ -337,7 +337,8 @@ __global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g
   // emission slots: Gaussian idx owns rows [first, first + cnt) of inst_grad; consecutive Gaussians
   // own consecutive runs, so the rows of this wave's 64 Gaussians are ONE contiguous block
   const uint32_t cnt = idx < p.P ? g.tiles_touched[ii] : 0u;
-  const uint32_t endi = idx < p.P ? g.point_offsets[ii] : 0u;
+  // (point_offsets counts inside the Gaussian's block of PRE_BLOCK; block_sums holds the blocks' exclusive offsets)
+  const uint32_t endi = idx < p.P ? g.block_sums[ii / PRE_BLOCK] + g.point_offsets[ii] : 0u;
   const uint32_t first = endi - cnt;
   // The wave's rows [F, E) of inst_grad are gathered in trips of 256; the first trip's flag and row loads (two dependent
   // round trips) are issued NOW, so that they overlap the input loads and the SH staging below.
@@ -582,7 +583,7 @@ __global__ __launch_bounds__(256) void k_gather_sums(int P, const int *__restric
   const size_t ii = (size_t)(idx < P ? idx : 0);
   const bool live = idx < P && counters[4] == 0u;  // (an aborted async frame contributes nothing)
   const uint32_t cnt = live ? g.tiles_touched[ii] : 0u;
-  const uint32_t endi_raw = live ? g.point_offsets[ii] : 0u;
+  const uint32_t endi_raw = live ? g.block_sums[ii / PRE_BLOCK] + g.point_offsets[ii] : 0u;  // (block-local scan + the block's offset)
   // owners' end slots, made non-decreasing over the lanes (culled / out-of-range owners repeat their predecessor's end)
   uint32_t endi = endi_raw;
 #pragma unroll

@@ -11,18 +11,21 @@
 #define TILE_PIXELS (TILE * TILE)
 #define PRE_BLOCK 256   // Gaussians per workgroup in the forward per-Gaussian kernels
 #define GB_BLOCK 64     // Gaussians per workgroup in the per-Gaussian backward (one wave: spreads P/64 groups over the CUs)
-#define REC_F4 3        // float4s per sorted-instance record
+#define REC_F4 3        // float4s per splat row / per-instance gradient row
 #define IGRAD_F 12      // floats per per-instance gradient slot (10 used, padded to 3 x float4)
 
-// ---- per-instance record (one per (tile, Gaussian) pair, in sorted order) ---------------
-//   r0 = (mean2D.x, mean2D.y, depth, gaussian id as bits)
+// ---- per-Gaussian splat row (one per Gaussian and view; GeomWS.splat) --------------------
+//   r0 = (mean2D.x, mean2D.y, tile rectangle x0 | y0 << 10 | w << 20, first emission slot inside the Gaussian's
+//         256-Gaussian block)
 //   r1 = (conic.a, conic.b, conic.c, opacity)
-//   r2 = (colour.r, colour.g, colour.b, emission slot u as bits)
-// The emission slot u (= first slot of the Gaussian + index of the tile inside its rectangle) is
-// where the reverse compositor stores this instance's partial gradients, so that the per-Gaussian
-// backward reads each Gaussian's partials as one contiguous run.
-// Written once after the sort so that the compositors stream contiguous 48-B records
-// instead of gathering four arrays through an index (forward.cu:491-498 / backward.cu:742-752).
+//   r2 = (colour.r, colour.g, colour.b, depth)
+// The compositors walk a tile's sorted id list (point_list) and GATHER these 48-byte rows -- one 16-byte-aligned row
+// instead of the four arrays the reference chases through the index (forward.cu:491-498 / backward.cu:742-752).
+// There is no per-(tile, Gaussian) copy of them any more: an opaque scene reaches a tenth of its tile lists, and the
+// rows of a frame (2.4 MB at cfg2) stay in the XCD's L2.
+// The emission slot u = block_sums[id / 256] + first slot + index of the tile inside the rectangle is where the reverse
+// compositor stores this instance's partial gradients, so that the per-Gaussian backward reads each Gaussian's partials
+// as one contiguous run.
 
 // ---- workspace layouts ------------------------------------------------------------------
 static inline __host__ __device__ size_t gsaj_align(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -35,12 +38,15 @@ struct GeomWS {  // per-Gaussian state (reference: GeometryState, rasterizer_imp
   float *rgb;             // [P*3]
   uint8_t *clamped;       // [P*3]
   uint32_t *tiles_touched;  // [P]
-  uint32_t *point_offsets;  // [P] inclusive scan of tiles_touched
+  uint32_t *point_offsets;  // [P] inclusive scan of tiles_touched INSIDE the Gaussian's block of PRE_BLOCK; + block_sums[block] = global
   int *internal_radii;      // [P]
-  uint32_t *block_sums;     // [nblk] per-workgroup totals, then exclusive offsets
+  uint32_t *block_sums;     // [nblk] per-workgroup totals, then (frame scan) their exclusive offsets
   float *tau_partials;      // [nblk*8] per-workgroup dL/dtau partial sums
-  float4 *splat;            // [P*3] packed per-Gaussian row the tile sort gathers with three 16-B loads:
-                            //   (mean2D.x, mean2D.y, rect x0|y0<<10|w<<20, first emission slot) (conic, opacity) (rgb, -)
+  float4 *splat;            // [P*3] the per-Gaussian row both compositors gather through the sorted id list (above)
+  float4 *splat16;          // [P*2] fp16-storage form of the row (GSAJ_FWD_RECORDS_FP16; written by k_pack_splat16):
+                            //   (mean2D.x, mean2D.y, depth, first emission slot) (half2 a b, half2 c o, half2 r g, half2 b 0)
+  uint4 *scat;              // [P] what the instance scatter reads: (depth bits, x0 | x1 << 16, y0 | y1 << 16, first emission
+                            //   slot inside the block); x1 == x0: the Gaussian has no tile
   float4 *gsum;             // [P*3] batched backward: the Gaussian's 10 reverse-compositor sums (its instance rows added in
                             //   emission order by k_gather_sums), read by k_gaussian_bwd_batch
 };
@@ -66,20 +72,22 @@ static inline __host__ __device__ size_t geom_carve(char *base, size_t P, GeomWS
   CARVE(block_sums, uint32_t, nblk);
   CARVE(tau_partials, float, ((P + GB_BLOCK - 1) / GB_BLOCK + 1) * 8);
   CARVE(splat, float4, P * 3);
+  CARVE(splat16, float4, P * 2);
+  CARVE(scat, uint4, P);
   CARVE(gsum, float4, P * 3);
   return off;
 }
 
 #define TILE_REP 1        // replicas of each tile's instance counter (1: contention is removed by LDS aggregation)
 #define LDS_TILES_MAX 8192  // images with more tiles than this bin with direct global atomics
-#define SORT_CAP 16384    // largest tile list the in-LDS tile sort handles (128 KB of the CU's 160 KB LDS); longer lists -> global radix fallback
+#define SORT_CAP 16384    // largest tile list sorted in ONE LDS pass (128 KB of the CU's 160 KB LDS); longer lists: LDS-sized chunks + merge passes
 #define N_COUNTERS 64     // frame counters: [0] num_rendered [1] error flags [2] longest tile list [3] tau ticket
                           //   [5] preprocess ticket (last workgroup runs the frame scan)
                           //   [4] abort (async forward: arena too small / tile list too long -> later kernels return)
 #define ERR_PREFILTERED 1u
 #define ERR_INTERNAL 2u
 #define ERR_CAPACITY 4u   // async forward: R exceeds the binning arena the caller provided
-#define ERR_TILE_LIST 8u  // async forward: a tile list exceeds SORT_CAP (the sync API falls back to the global sort)
+#define ERR_TILE_LIST 8u  // (no longer raised: tile lists of any length are sorted on the device)
 
 struct ImageWS {  // reference: ImageState, rasterizer_impl.h:46-53
   float *final_T;         // [H*W]
@@ -114,15 +122,12 @@ static inline __host__ __device__ size_t image_carve(char *base, int W, int H, I
 }
 
 struct BinWS {  // reference: BinningState, rasterizer_impl.h:55-66
-  uint64_t *keys_unsorted;  // [R] fast path: (depth bits << 32 | id) grouped by tile; fallback: (tile << 32 | depth bits)
-  uint64_t *keys;           // [R]
-  uint32_t *vals_unsorted;  // [R]
+  uint64_t *keys_unsorted;  // [R] (depth bits << 32 | id), grouped by tile (k_scatter_instances)
+  uint64_t *keys;           // [R] second key buffer: merge passes of tile lists longer than the LDS sort capacity
   uint32_t *point_list;     // [R] sorted Gaussian ids
-  float4 *records;          // [R*3]
   float4 *inst_grad;        // [R*3] per-instance partial gradients (backward), indexed by emission slot
   uint8_t *reached;         // [R] by emission slot: 1 = the reverse compositor wrote that row, 0 = no pixel of the tile got that far
-  char *sort_temp;
-  size_t sort_temp_bytes;
+                            //   (zeroed by the tile sort, set by the reverse compositor)
 };
 
 // ---- batched multi-view launches (gsaj_rasterize_*_batch): K views of ONE Gaussian map -------------------------------
@@ -142,6 +147,7 @@ __device__ __forceinline__ GeomWS geom_view(GeomWS g, size_t off) {
   g.tiles_touched = gsaj_shift(g.tiles_touched, off); g.point_offsets = gsaj_shift(g.point_offsets, off);
   g.internal_radii = gsaj_shift(g.internal_radii, off); g.block_sums = gsaj_shift(g.block_sums, off);
   g.tau_partials = gsaj_shift(g.tau_partials, off); g.splat = gsaj_shift(g.splat, off); g.gsum = gsaj_shift(g.gsum, off);
+  g.splat16 = gsaj_shift(g.splat16, off); g.scat = gsaj_shift(g.scat, off);
   return g;
 }
 __device__ __forceinline__ ImageWS image_view(ImageWS m, size_t off) {
@@ -153,20 +159,14 @@ __device__ __forceinline__ ImageWS image_view(ImageWS m, size_t off) {
 }
 #endif
 
-size_t gsaj_sort_temp_bytes(int R);  // binning.hip
-
-static inline size_t bin_carve(char *base, size_t R, size_t sort_temp_bytes, BinWS *g) {
+static inline size_t bin_carve(char *base, size_t R, BinWS *g) {
   size_t off = 0;
   size_t Rn = R ? R : 1;
   CARVE(keys_unsorted, uint64_t, Rn);
   CARVE(keys, uint64_t, Rn);
-  CARVE(vals_unsorted, uint32_t, Rn);
   CARVE(point_list, uint32_t, Rn);
-  CARVE(records, float4, Rn * REC_F4);
   CARVE(inst_grad, float4, Rn * REC_F4);
   CARVE(reached, uint8_t, Rn);
-  CARVE(sort_temp, char, sort_temp_bytes);
-  if (g) g->sort_temp_bytes = sort_temp_bytes;
   return off;
 }
 #undef CARVE
@@ -211,20 +211,17 @@ struct FwdParams {
 
 int launch_preprocess(const FwdParams &p, int *radii, int *n_touched, const GeomWS &g, const ImageWS &im, ViewStrides vs,
                       hipStream_t s);
-// radii: [views, P]; features: colors_precomp [P,3] shared by every view, or NULL = the view's own SH colours (g.rgb)
-int launch_tile_binning(int P, int R, int sort_cap, int rec16, int grid_x, int grid_y, const int *radii, const float *features, const GeomWS &g,
-                        const BinWS &b, const ImageWS &im, int views, ViewStrides vs, hipStream_t s);
-int launch_emit_keys(int P, int grid_x, int grid_y, const int *radii, const GeomWS &g, const BinWS &b, const ImageWS &im,
-                     hipStream_t s);
-int launch_sort(int R, int end_bit, const BinWS &b, hipStream_t s);
-int launch_ranges_and_records(int P, int R, int grid_x, int grid_y, const int *radii, const float *features,
-                              const GeomWS &g, const BinWS &b, const ImageWS &im, hipStream_t s);
+// tile binning of `views` frames: instance scatter -> per-tile (depth, id) sort -> point_list, ranges, cleared `reached` flags.
+// sort_cap: LDS sort capacity in keys the caller sizes for (rounded up to a power of two in [128, SORT_CAP]); longer lists take
+// the chunk + merge path inside the same kernel.  rec16: also write the fp16-storage rows (GeomWS.splat16).
+int launch_tile_binning(int P, int sort_cap, int rec16, int grid_x, int grid_y, const GeomWS &g, const BinWS &b, const ImageWS &im,
+                        int views, ViewStrides vs, hipStream_t s);
 // out_color [views,3,H,W], out_depth / out_opacity [views,1,H,W], n_touched [views,P]
-int launch_render_forward(int P, int W, int H, int grid_x, int grid_y, const float *bg, const BinWS &b, const ImageWS &im,
-                          float *out_color, float *out_depth, float *out_opacity, int *n_touched, int views, ViewStrides vs,
-                          hipStream_t s);
+int launch_render_forward(int P, int W, int H, int grid_x, int grid_y, const float *bg, const GeomWS &g, const BinWS &b,
+                          const ImageWS &im, float *out_color, float *out_depth, float *out_opacity, int *n_touched, int views,
+                          ViewStrides vs, hipStream_t s);
 // dL_dpix [views,3,H,W], dL_dpix_depth [views,1,H,W]
-int launch_render_backward(int R, int W, int H, int grid_x, int grid_y, const float *bg, const BinWS &b,
+int launch_render_backward(int R, int W, int H, int grid_x, int grid_y, const float *bg, const GeomWS &g, const BinWS &b,
                            const ImageWS &im, const float *dL_dpix, const float *dL_dpix_depth, int views, ViewStrides vs,
                            hipStream_t s);
 struct BwdParams {
@@ -297,12 +294,12 @@ __device__ __forceinline__ float3 cross3(float3 a, float3 b) {
 }
 #endif
 
-// ---- instance record formats ------------------------------------------------------------------------------
-// fp32 (default): 3 float4 = {mean x, mean y, depth, id | conic a, b, c, opacity | r, g, b, emission slot}.
-// fp16 storage (gsaj_set_record_format(16); BASELINE config 5 "fp16 splat with fp32 Jacobian accumulation"): 2 float4 =
-// {mean x, mean y, depth, emission slot | half2(a, b), half2(c, opacity), half2(r, g), half2(b, 0)} -- positions, depth and
-// every accumulation stay fp32; conic / opacity / colour are rounded to half once, when the sort kernel writes the
-// record.  The Gaussian id is then taken from point_list.  counters[7] of the frame says which format the records have.
+// ---- splat row formats ----------------------------------------------------------------------------------------
+// fp32 (default): GeomWS.splat, 3 float4 = {mean x, mean y, rect, first slot | conic a, b, c, opacity | r, g, b, depth}.
+// fp16 storage (GSAJ_FWD_RECORDS_FP16; BASELINE config 5 "fp16 splat with fp32 Jacobian accumulation"): GeomWS.splat16, 2 float4 =
+// {mean x, mean y, depth, first slot | half2(a, b), half2(c, opacity), half2(r, g), half2(b, 0)} -- positions, depth and
+// every accumulation stay fp32; conic / opacity / colour are rounded to half once (k_pack_splat16).  The tile rectangle
+// then comes from GeomWS.scat (reverse compositor only).  counters[7] of the frame says which form the frame uses.
 #define REC16_F4 2
 #ifdef __HIPCC__
 #include <hip/hip_fp16.h>
@@ -311,23 +308,25 @@ __device__ __forceinline__ uint32_t gsaj_pack_h2(float a, float b) {
   return *reinterpret_cast<const uint32_t *>(&h);
 }
 __device__ __forceinline__ float2 gsaj_unpack_h2(uint32_t u) { return __half22float2(*reinterpret_cast<const __half2 *>(&u)); }
-__device__ __forceinline__ void gsaj_load_record(const float4 *__restrict__ records, const uint32_t *__restrict__ point_list, size_t k,
-                                                 bool rec16, float4 &q0, float4 &q1, float4 &q2) {
+// Gather Gaussian `id`'s row: q0 = (mean x, mean y, depth, first slot), q1 = (conic a, b, c, opacity), q2 = (r, g, b, rect pack
+// x0 | y0 << 10 | w << 20 -- fp32 rows only; 0 for fp16 rows, whose rectangle is in GeomWS.scat).
+__device__ __forceinline__ void gsaj_load_row(const float4 *__restrict__ splat, const float4 *__restrict__ splat16, uint32_t id,
+                                              bool rec16, float4 &q0, float4 &q1, float4 &q2) {
   if (!rec16) {
-    const float4 *s = records + k * REC_F4;
-    q0 = s[0], q1 = s[1], q2 = s[2];
+    const float4 *s = splat + (size_t)id * REC_F4;
+    const float4 r0 = s[0], r1 = s[1], r2 = s[2];
+    q0 = make_float4(r0.x, r0.y, r2.w, r0.w);
+    q1 = r1;
+    q2 = make_float4(r2.x, r2.y, r2.z, r0.z);
     return;
   }
-  const float4 *s = records + k * REC16_F4;
+  const float4 *s = splat16 + (size_t)id * REC16_F4;
   const float4 p0 = s[0], p1 = s[1];
   const float2 ab = gsaj_unpack_h2(__float_as_uint(p1.x)), co = gsaj_unpack_h2(__float_as_uint(p1.y));
   const float2 rg = gsaj_unpack_h2(__float_as_uint(p1.z)), bz = gsaj_unpack_h2(__float_as_uint(p1.w));
-  q0 = make_float4(p0.x, p0.y, p0.z, point_list ? __uint_as_float(point_list[k]) : 0.f);
+  q0 = p0;
   q1 = make_float4(ab.x, ab.y, co.x, co.y);
-  q2 = make_float4(rg.x, rg.y, bz.x, p0.w);
-}
-__device__ __forceinline__ uint32_t gsaj_record_emission_slot(const float4 *__restrict__ records, size_t k, bool rec16) {
-  return __float_as_uint(rec16 ? records[k * REC16_F4].w : records[k * REC_F4 + 2].w);
+  q2 = make_float4(rg.x, rg.y, bz.x, 0.f);
 }
 #endif
 

@@ -103,7 +103,7 @@ __device__ __forceinline__ float3 sh_to_rgb(int deg, float3 pos, float3 campos, 
   return make_float3(out[0], out[1], out[2]);
 }
 
-__device__ void frame_scan(int nblk, int tiles, int capacity, int sort_cap, uint32_t *block_sums, ImageWS im, uint32_t *lds_tiles);
+__device__ void frame_scan(int nblk, int tiles, int capacity, uint32_t *block_sums, ImageWS im, uint32_t *lds_tiles);
 
 GSAJ_TRACE_DEFINE(pre)
 
@@ -137,11 +137,12 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__re
     __syncthreads();
   }
   uint32_t touched = 0;
+  uint32_t rect_x = 0, rect_y = 0;  // x0 | x1 << 16, y0 | y1 << 16 (GeomWS.scat)
+  float depth = 0.f;
   if (idx < p.P) {
     int my_radius_i = 0;
     uint32_t rect_pack = 0;
     float2 xy = make_float2(0.f, 0.f);
-    float depth = 0.f;
     float4 con_o = make_float4(0.f, 0.f, 0.f, 0.f);
     float3 rgb = make_float3(0.f, 0.f, 0.f);
     uint8_t cl[3] = {0, 0, 0};
@@ -200,6 +201,8 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__re
             else rgb = sh_to_rgb(p.D, p_orig, cam, p.shs + (size_t)idx * p.M * 3, cl);
           }
           rect_pack = (uint32_t)x0 | ((uint32_t)y0 << 10) | ((uint32_t)(x1 - x0) << 20);
+          rect_x = (uint32_t)x0 | ((uint32_t)x1 << 16);
+          rect_y = (uint32_t)y0 | ((uint32_t)y1 << 16);
           depth = p_view.z;
           my_radius_i = (int)my_radius;
           xy = pim;
@@ -230,9 +233,10 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__re
     }
     g.tiles_touched[idx] = touched;
     if (p.colors_precomp) rgb = ld3(p.colors_precomp, idx);
+    // the row both compositors gather through the sorted id list (its .w of the first quarter, the first emission slot, follows the scan)
     g.splat[3 * (size_t)idx + 0] = make_float4(xy.x, xy.y, __uint_as_float(rect_pack), 0.f);
     g.splat[3 * (size_t)idx + 1] = con_o;
-    g.splat[3 * (size_t)idx + 2] = make_float4(rgb.x, rgb.y, rgb.z, 0.f);
+    g.splat[3 * (size_t)idx + 2] = make_float4(rgb.x, rgb.y, rgb.z, depth);
   }
   TRP(0)
   // block-local inclusive scan of tiles_touched (Hillis-Steele over 256 lanes)
@@ -250,7 +254,13 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__re
     scan[tid] += v;
     __syncthreads();
   }
-  if (idx < p.P) g.point_offsets[idx] = scan[tid];
+  if (idx < p.P) {
+    // emission slots are counted inside the block; + block_sums[block] (its exclusive offset once the frame scan below has run)
+    const uint32_t first = scan[tid] - touched;
+    g.point_offsets[idx] = scan[tid];
+    reinterpret_cast<float *>(g.splat)[12 * (size_t)idx + 3] = __uint_as_float(first);
+    g.scat[idx] = make_uint4(__float_as_uint(depth), rect_x, rect_y, first);
+  }
   if (tid == PRE_BLOCK - 1)  // write-through (sc1): read by the last workgroup below
     __hip_atomic_store(&g.block_sums[blockIdx.x], scan[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // ---- the last workgroup to arrive scans the per-workgroup totals and the tile histogram ----
@@ -265,7 +275,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__re
     s_last = __hip_atomic_fetch_add(&im.counters[5], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
   __syncthreads();
   TRP(2)
-  if (s_last) frame_scan((int)gridDim.x, tiles, p.capacity, p.sort_cap, g.block_sums, im, use_lds ? hist : nullptr);
+  if (s_last) frame_scan((int)gridDim.x, tiles, p.capacity, g.block_sums, im, use_lds ? hist : nullptr);
   TRP(3)
   GSAJ_TRACE_END(pre)
 #ifdef GSAJ_BLOCK_TRACE
@@ -398,7 +408,7 @@ __device__ uint32_t tile_scan_and_schedule(int tiles, ImageWS im, uint32_t *len,
 // rasterizer_impl.cu:327 and a separate launch): (1) exclusive offsets of the per-workgroup Gaussian
 // totals and the grand total R; (2) exclusive offsets of the per-tile histogram; (3) the longest
 // tile list; (4) for the async forward, the device-side capacity check.
-__device__ void frame_scan(int nblk, int tiles, int capacity, int sort_cap, uint32_t *block_sums, ImageWS im, uint32_t *lds_tiles) {
+__device__ void frame_scan(int nblk, int tiles, int capacity, uint32_t *block_sums, ImageWS im, uint32_t *lds_tiles) {
   const uint32_t R = tail_exclusive_scan(block_sums, block_sums, nblk, nullptr);
   uint32_t m = 0, R2;
   if (lds_tiles) {
@@ -414,8 +424,7 @@ __device__ void frame_scan(int nblk, int tiles, int capacity, int sort_cap, uint
     uint32_t err = 0u;
     if (R2 != R) err |= ERR_INTERNAL;  // cannot happen; guards the invariant sum(tile lists) == sum(tiles_touched)
     if (capacity > 0) {  // async forward: nobody on the host will look at R before the next kernels run
-      if (R > (uint32_t)capacity) err |= ERR_CAPACITY;
-      if (m > (uint32_t)(sort_cap > 0 ? sort_cap : SORT_CAP)) err |= ERR_TILE_LIST;
+      if (R > (uint32_t)capacity) err |= ERR_CAPACITY;  // (a tile list of any length is sorted on the device: k_tile_sort)
       if (err) {
         im.counters[4] = 1u;  // the remaining kernels of this frame return immediately
         atomicAdd(&im.sticky[0], 1u);
@@ -425,102 +434,121 @@ __device__ void frame_scan(int nblk, int tiles, int capacity, int sort_cap, uint
   }
 }
 
-// Fast path: every Gaussian drops (depth bits << 32 | id) into a free slot of each touched tile's
-// list segment.  A workgroup first counts its instances per tile in LDS, reserves one contiguous
-// slot range per tile with a single coalesced pass of returning global atomics, then hands out the
-// slots with LDS atomics.  Slot order inside a tile is arbitrary; the tile sort orders by
-// (depth, id), a total order, so the final lists are deterministic.
-// Also turns point_offsets into the global inclusive scan (emission slots for the backward).
+// ---- instance scatter ----------------------------------------------------------------------------------------------
+// Every Gaussian drops (depth bits << 32 | id) into a free slot of each touched tile's list segment (duplicateWithKeys,
+// rasterizer_impl.cu:70-111, without the tile id in the key: the segments are the tiles).  Slot order inside a tile is
+// arbitrary; the tile sort orders by (depth, id), a total order, so the final lists are deterministic.
+//
+// Who writes what (MI355X: 8 XCDs, each with its own L2 that writes partial lines back on its own).  A tile's segment is a
+// few hundred contiguous 8-byte keys; written by workgroups of all eight XCDs, every 128-byte line of it left eight L2s in
+// pieces (WRITE_SIZE 4x the bytes, profiles/r02_pmc_summary.json).  So the tile ROWS are dealt into SCAT_CLS = 8 classes
+// (row y belongs to class y % 8) and a workgroup emits only its class: blockIdx.x % 8 = class = the XCD the dispatcher is
+// observed to put the workgroup on (speed only -- any placement gives the same lists), so one L2 assembles a segment's
+// lines.  The workgroup covers SCAT_GPT x 256 Gaussians (eight workgroups, one per class, read the same 16-byte `scat`
+// entries): per tile of its class it counts in LDS, reserves ONE slot range with a returning global atomic (1/5 of the
+// atomics a 256-Gaussian workgroup over all tiles needed, and runs of ~13 keys instead of ~2), then hands the slots out
+// with LDS atomics.
+#ifndef SCAT_CLS
+#define SCAT_CLS 8
+#endif
+#ifndef SCAT_GPT
+#define SCAT_GPT 8
+#endif
+#define SCAT_LDS_TILES 8192  // class-local tiles the LDS counters hold (64 KB); more: direct global atomics
 GSAJ_TRACE_DEFINE(scat)
 
-__global__ __launch_bounds__(PRE_BLOCK) void k_scatter_instances(int P, int gx, int gy, const int *__restrict__ radii,
-                                                                 GeomWS g, ImageWS im, uint64_t *__restrict__ inst_key,
-                                                                 ViewStrides vs) {
-  extern __shared__ uint32_t lds[];  // [2*tiles]: count -> reserved base, fill cursor
+__global__ __launch_bounds__(PRE_BLOCK) void k_scatter_instances(int P, int gx, int gy, GeomWS g, ImageWS im,
+                                                                 uint64_t *__restrict__ inst_key, ViewStrides vs) {
+  extern __shared__ uint32_t lds[];  // [2 * ltiles]: count -> reserved base, fill cursor (class-local tile index)
   {
     const size_t view = blockIdx.y;
     g = geom_view(g, view * vs.geom);
     im = image_view(im, view * vs.image);
     inst_key = gsaj_shift(inst_key, view * vs.bin);
-    radii += view * (size_t)P;
   }
   if (im.counters[4]) return;  // aborted async frame
   GSAJ_TRACE_BEGIN(scat)
-#ifdef GSAJ_BLOCK_TRACE
-  unsigned long long trs_[4] = {0, 0, 0, 0}, trs_t = wall_clock64();
-#define TRS(i) { const unsigned long long n_ = wall_clock64(); trs_[i] += n_ - trs_t; trs_t = n_; }
-#else
-#define TRS(i)
-#endif
   const int tid = threadIdx.x;
-  const int idx = blockIdx.x * PRE_BLOCK + tid;
-  const int tiles = gx * gy;
-  const bool use_lds = tiles <= LDS_TILES_MAX;
-  uint32_t *cnt = lds, *fill = lds + tiles;
+  const int cls = (int)(blockIdx.x % SCAT_CLS), gb = (int)(blockIdx.x / SCAT_CLS);
+  const int rows_c = (gy - cls + SCAT_CLS - 1) / SCAT_CLS;  // tile rows y = cls + SCAT_CLS * j < gy
+  const int ltiles = rows_c > 0 ? rows_c * gx : 0;
+  const bool use_lds = ((gy + SCAT_CLS - 1) / SCAT_CLS) * gx <= SCAT_LDS_TILES;
+  uint32_t *cnt = lds, *fill = lds + ltiles;
   if (use_lds) {
-    for (int t = tid; t < 2 * tiles; t += PRE_BLOCK) lds[t] = 0u;
+    for (int t = tid; t < 2 * ltiles; t += PRE_BLOCK) lds[t] = 0u;
     __syncthreads();
   }
-  int r = 0, x0 = 0, y0 = 0, x1 = 0, y1 = 0;
-  uint64_t key = 0;
-  if (idx < P) {
-    const uint32_t incl = g.block_sums[blockIdx.x] + g.point_offsets[idx];
-    g.point_offsets[idx] = incl;
-    reinterpret_cast<float *>(g.splat)[12 * (size_t)idx + 3] = __uint_as_float(incl - g.tiles_touched[idx]);
-    r = radii[idx];
-    const float2 xy = g.means2D[idx];  // requested together with the radius, not after it (latency-bound kernel)
-    const float dep = g.depths[idx];
-    if (r > 0) {
-      tile_rect(xy.x, xy.y, r, gx, gy, gsaj_tile_band(im.sticky), x0, y0, x1, y1);
-      key = ((uint64_t)__float_as_uint(dep) << 32) | (uint32_t)idx;
-    }
+  // this thread's Gaussians: all requested up front
+  uint4 sc[SCAT_GPT];
+#pragma unroll
+  for (int i = 0; i < SCAT_GPT; i++) {
+    const int idx = (gb * SCAT_GPT + i) * PRE_BLOCK + tid;
+    sc[i] = idx < P ? g.scat[idx] : make_uint4(0u, 0u, 0u, 0u);
   }
-  if (!use_lds) {
-    for (int y = y0; y < y1; y++)
-      for (int x = x0; x < x1; x++) {
-        const int c = y * gx + x;
-        inst_key[im.tile_offset[c] + atomicAdd(&im.tile_cursor[c], 1u)] = key;
-      }
+  // rows of this class inside [y0, y1): y = ys, ys + SCAT_CLS, ...
+#define SCAT_FOR_EACH_TILE(BODY)                                                                     \
+  _Pragma("unroll") for (int i = 0; i < SCAT_GPT; i++) {                                             \
+    const int x0 = (int)(sc[i].y & 0xffffu), x1 = (int)(sc[i].y >> 16);                             \
+    const int y0 = (int)(sc[i].z & 0xffffu), y1 = (int)(sc[i].z >> 16);                             \
+    if (x1 > x0) {                                                                                   \
+      const int idx = (gb * SCAT_GPT + i) * PRE_BLOCK + tid;                                         \
+      const uint64_t key = ((uint64_t)sc[i].x << 32) | (uint32_t)idx;                                \
+      (void)key;                                                                                     \
+      const int ys = y0 + ((cls - y0) % SCAT_CLS + SCAT_CLS) % SCAT_CLS;                             \
+      for (int y = ys; y < y1; y += SCAT_CLS)                                                        \
+        for (int x = x0; x < x1; x++) {                                                              \
+          const int lt = (y / SCAT_CLS) * gx + x; /* class-local tile */                             \
+          const int t = y * gx + x;               /* tile */                                         \
+          (void)lt; (void)t;                                                                         \
+          BODY                                                                                       \
+        }                                                                                            \
+    }                                                                                                \
+  }
+  if (!use_lds) {  // (more than 8 x 8192 tiles: beyond 16 384 x 2048 pixels)
+    SCAT_FOR_EACH_TILE({ inst_key[im.tile_offset[t] + atomicAdd(&im.tile_cursor[t], 1u)] = key; })
     return;
   }
-  TRS(0)
-  for (int y = y0; y < y1; y++)
-    for (int x = x0; x < x1; x++) atomicAdd(&cnt[y * gx + x], 1u);
+  SCAT_FOR_EACH_TILE({ atomicAdd(&cnt[lt], 1u); })
   __syncthreads();
-  TRS(1)
-  // reserve this workgroup's slot range in every tile it touches: returning atomics, issued eight at
-  // a time so their round trips overlap (one s_waitcnt per batch instead of one per tile)
-  for (int t0 = 0; t0 < tiles; t0 += 8 * PRE_BLOCK) {
+  // reserve this workgroup's slot range in every tile of its class it touches: returning atomics, eight to a batch so
+  // that their round trips overlap (one s_waitcnt per batch instead of one per tile)
+  for (int l0 = 0; l0 < ltiles; l0 += 8 * PRE_BLOCK) {
     uint32_t c[8], base[8], off[8];
 #pragma unroll
     for (int b = 0; b < 8; b++) {
-      const int t = t0 + b * PRE_BLOCK + tid;
-      c[b] = t < tiles ? cnt[t] : 0u;
-      off[b] = t < tiles ? im.tile_offset[t] : 0u;  // in flight together with the atomics
-      base[b] = c[b] ? atomicAdd(&im.tile_cursor[t], c[b]) : 0u;
+      const int lt = l0 + b * PRE_BLOCK + tid;
+      c[b] = 0u, off[b] = 0u, base[b] = 0u;
+      if (lt < ltiles) {
+        const int j = lt / gx;
+        const int t = (j * SCAT_CLS + cls) * gx + (lt - j * gx);
+        c[b] = cnt[lt];
+        off[b] = im.tile_offset[t];  // in flight together with the atomics
+        if (c[b]) base[b] = atomicAdd(&im.tile_cursor[t], c[b]);
+      }
     }
 #pragma unroll
     for (int b = 0; b < 8; b++) {
-      const int t = t0 + b * PRE_BLOCK + tid;
-      if (c[b]) cnt[t] = off[b] + base[b];
+      const int lt = l0 + b * PRE_BLOCK + tid;
+      if (c[b]) cnt[lt] = off[b] + base[b];
     }
   }
   __syncthreads();
-  TRS(2)
-  for (int y = y0; y < y1; y++)
-    for (int x = x0; x < x1; x++) {
-      const int c = y * gx + x;
-      inst_key[cnt[c] + atomicAdd(&fill[c], 1u)] = key;
-    }
-  TRS(3)
+  SCAT_FOR_EACH_TILE({ inst_key[cnt[lt] + atomicAdd(&fill[lt], 1u)] = key; })
+#undef SCAT_FOR_EACH_TILE
   GSAJ_TRACE_END(scat)
-#ifdef GSAJ_BLOCK_TRACE
-  if ((threadIdx.x & 63) == 0) {
-    unsigned long long *t = g_trace_scat + 4 * (blockIdx.x * (PRE_BLOCK / 64) + (threadIdx.x >> 6));
-    t[2] = (trs_[0] << 32) | trs_[1];
-    t[3] = (trs_[2] << 32) | trs_[3];
-  }
-#endif
+}
+
+// fp16-storage rows (GSAJ_FWD_RECORDS_FP16): conic / opacity / colour of every Gaussian rounded to half ONCE, here; mean2D,
+// depth and the emission slot stay 32-bit.  One 32-byte row instead of 48 for the compositors to gather.
+__global__ __launch_bounds__(256) void k_pack_splat16(int P, GeomWS g, const uint32_t *__restrict__ counters, ViewStrides vs) {
+  g = geom_view(g, (size_t)blockIdx.y * vs.geom);
+  if (gsaj_shift(counters, (size_t)blockIdx.y * vs.image)[4]) return;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= P) return;
+  const float4 a = g.splat[3 * (size_t)idx + 0], bq = g.splat[3 * (size_t)idx + 1], c = g.splat[3 * (size_t)idx + 2];
+  g.splat16[2 * (size_t)idx + 0] = make_float4(a.x, a.y, c.w, a.w);
+  g.splat16[2 * (size_t)idx + 1] = make_float4(__uint_as_float(gsaj_pack_h2(bq.x, bq.y)), __uint_as_float(gsaj_pack_h2(bq.z, bq.w)),
+                                              __uint_as_float(gsaj_pack_h2(c.x, c.y)), __uint_as_float(gsaj_pack_h2(c.z, 0.f)));
 }
 
 // ---- register exchange for the wave-local stages of the tile sort -------------------------------
@@ -575,26 +603,132 @@ __device__ __forceinline__ void local_merges(uint64_t &A, uint64_t &B, int lane,
   if constexpr (K < 128) local_merges<2 * K>(A, B, lane, ia, ib, m);
 }
 
-// One workgroup per tile: bitonic sort of the tile's (depth, id) keys in LDS, then the sorted
-// Gaussian ids, the 48-byte instance records, the emission-slot -> sorted-position map and the
-// tile's [start, end) range are written in one pass.
+// The strides >= 128 of the merge of size k (through LDS, workgroup barriers), then the seven chunk-local strides in registers.
+// asc_all: every comparator ascending (the final merge of a bitonic sequence of length k = m).
+__device__ __forceinline__ void lds_merge_level(uint64_t *keys, int m, int k, bool asc_all, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int j = k >> 1; j >= 128; j >>= 1) {
+    for (int i = tid; i < (m >> 1); i += 256) {
+      const int l = ((i & ~(j - 1)) << 1) | (i & (j - 1)), r = l + j;
+      const uint64_t a = keys[l], b = keys[r];
+      if ((a > b) == (asc_all || (l & k) == 0)) {
+        keys[l] = b;
+        keys[r] = a;
+      }
+    }
+    __syncthreads();
+  }
+  for (int chunk = wave; chunk * 128 < m; chunk += 4) {
+    const int ia = chunk * 128 + lane, ib = ia + 64;
+    uint64_t A = keys[ia], B = keys[ib];
+    const bool asc = asc_all || (ia & k) == 0;  // k >= 256: one direction for the whole chunk
+    merge_strides<64>(A, B, lane, asc, asc);
+    keys[ia] = A;
+    keys[ib] = B;
+  }
+  __syncthreads();
+}
+
+// Bitonic sort of keys[0, m) in LDS, m a power of two (>= 2), ascending; the caller's stores to `keys` need no barrier before
+// the call only if each thread reads what it wrote -- so: barrier before.  Comparators with stride <= 64 pair keys inside one
+// aligned 128-key chunk, and a wave holds a chunk in REGISTERS (lane l: keys l and l + 64): stride 64 is in-lane, strides
+// 32 / 16 use v_permlane32_swap / v_permlane16_swap, strides 8..1 DPP -- an LDS round trip per stage was the latency of this
+// kernel.  So the first 28 stages (k = 2..128: every chunk sorted on its own) never touch LDS, and for k >= 256 only the
+// strides >= 128 do (with workgroup barriers), followed by the seven chunk-local stages in registers again.
+__device__ __forceinline__ void lds_bitonic_sort(uint64_t *keys, int m, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int chunk = wave; chunk * 128 < m; chunk += 4) {
+    const int ia = chunk * 128 + lane, ib = ia + 64;
+    uint64_t A = ia < m ? keys[ia] : ~0ull, B = ib < m ? keys[ib] : ~0ull;
+    local_merges<2>(A, B, lane, ia, ib, m);
+    if (ia < m) keys[ia] = A;
+    if (ib < m) keys[ib] = B;
+  }
+  __syncthreads();
+  for (int k = 256; k <= m; k <<= 1) lds_merge_level(keys, m, k, false, tid);
+}
+
+// A tile list longer than the LDS holds (n > T keys; the reference's global radix sort takes any length,
+// rasterizer_impl.cu:353-368).  (1) chunks of T keys are sorted in LDS, a -> b; (2) merge passes b -> a -> b ... over runs of
+// T, 2T, ...: the output of a pair of runs is produced T keys at a time -- the merge-path split of every T-th output
+// diagonal is found by binary search (one thread per diagonal), the two input pieces (together T keys) are loaded as
+// [A ascending | +inf | B descending], a bitonic sequence that ONE merge level sorts.  Everything inside the tile's own
+// workgroup and key segment; returns the buffer that holds the sorted keys.
+__device__ const uint64_t *sort_long_list(uint64_t *lds, int T, uint64_t *a, uint64_t *b, int n, int tid) {
+  __shared__ uint32_t split_s[PRE_BLOCK + 1];
+  for (int c0 = 0; c0 < n; c0 += T) {
+    const int len = min(T, n - c0);
+    for (int i = tid; i < T; i += 256) lds[i] = i < len ? a[c0 + i] : ~0ull;
+    __syncthreads();
+    lds_bitonic_sort(lds, T, tid);
+    for (int i = tid; i < len; i += 256) b[c0 + i] = lds[i];
+    __syncthreads();
+  }
+  uint64_t *src = b, *dst = a;
+  for (long long width = T; width < (long long)n; width <<= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this workgroup's stores of the previous pass, before anyone reads them
+    __syncthreads();
+    for (long long p0 = 0; p0 < (long long)n; p0 += 2 * width) {
+      const int la = (int)min(width, (long long)n - p0);
+      const int lb = (int)max(0ll, min(width, (long long)n - p0 - width));
+      const uint64_t *A = src + p0, *B = src + p0 + width;
+      uint64_t *D = dst + p0;
+      if (lb == 0) {
+        for (int i = tid; i < la; i += 256) D[i] = A[i];
+        continue;
+      }
+      const int tot = la + lb, nblk = (tot + T - 1) / T;
+      for (int j0 = 0; j0 < nblk; j0 += PRE_BLOCK) {
+        for (int t = tid; t <= PRE_BLOCK; t += 256) {  // merge-path split of diagonal d: how many of the first d outputs come from A
+          const long long dl = (long long)(j0 + t) * T;
+          const int d = (int)min(dl, (long long)tot);
+          int lo = max(0, d - lb), hi = min(d, la);
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (A[mid] <= B[d - 1 - mid]) lo = mid + 1;
+            else hi = mid;
+          }
+          split_s[t] = (uint32_t)lo;
+        }
+        __syncthreads();
+        for (int j = j0; j < min(nblk, j0 + PRE_BLOCK); j++) {
+          const int a0 = (int)split_s[j - j0], a1 = (int)split_s[j - j0 + 1];
+          const int d0 = j * T, d1 = min(tot, d0 + T);
+          const int b0 = d0 - a0, cA = a1 - a0, cB = (d1 - a1) - b0;
+          for (int i = tid; i < T; i += 256) lds[i] = i < cA ? A[a0 + i] : (i >= T - cB ? B[b0 + (T - 1 - i)] : ~0ull);
+          __syncthreads();
+          lds_merge_level(lds, T, T, true, tid);
+          for (int i = tid; i < cA + cB; i += 256) D[d0 + i] = lds[i];
+          __syncthreads();
+        }
+      }
+    }
+    uint64_t *t = src;
+    src = dst;
+    dst = t;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  return src;
+}
+
+// One workgroup per tile: sort of the tile's (depth, id) keys -> the sorted Gaussian ids (point_list) and the tile's [start, end)
+// range (cub::DeviceRadixSort + identifyTileRanges, rasterizer_impl.cu:353-368, 116-138); the tile's `reached` flags cleared.
 GSAJ_TRACE_DEFINE(sort)
 
-__global__ __launch_bounds__(256) void k_tile_sort_records(int gx, int gy, const int *__restrict__ radii,
-                                                           const float *__restrict__ features, GeomWS g, ImageWS im,
-                                                           const uint64_t *__restrict__ inst_key,
-                                                           uint32_t *__restrict__ point_list,
-                                                           float4 *__restrict__ records, int cap, int pass, int rec16, ViewStrides vs) {
+__global__ __launch_bounds__(256) void k_tile_sort(ImageWS im, uint64_t *__restrict__ inst_key, uint64_t *__restrict__ keys_b,
+                                                   uint32_t *__restrict__ point_list, uint8_t *__restrict__ reached, int cap,
+                                                   int pass, int rec16, ViewStrides vs) {
   {
     const size_t view = blockIdx.y;
-    g = geom_view(g, view * vs.geom);
     im = image_view(im, view * vs.image);
     inst_key = gsaj_shift(inst_key, view * vs.bin);
+    keys_b = gsaj_shift(keys_b, view * vs.bin);
     point_list = gsaj_shift(point_list, view * vs.bin);
-    records = gsaj_shift(records, view * vs.bin);
+    reached = gsaj_shift(reached, view * vs.bin);
   }
-  // `cap` keys of dynamic LDS: the host sizes it to the longest tile list (sync path: known exactly; async path: the
-  // caller's tile_list_capacity, checked on the device by frame_scan), so short lists do not pay for 32 KB per workgroup
+  // `cap` keys of dynamic LDS: the host sizes it to the longest tile list it expects (sync path: known exactly; async path: the
+  // caller's tile_list_capacity), so short lists do not pay for 32 KB per workgroup; a longer list takes sort_long_list
   extern __shared__ uint64_t keys[];
   if (im.counters[4]) return;  // aborted async frame
   GSAJ_TRACE_BEGIN(sort)
@@ -610,86 +744,32 @@ __global__ __launch_bounds__(256) void k_tile_sort_records(int gx, int gy, const
   // At cfg5 (lists of ~3300, a few above 4096) one launch ran at 2 workgroups per CU: 4.2 of the window's 10.5 ms.
   if (pass != 2) {
     if (tid == 0) im.ranges[tile] = n > 0 ? make_uint2(beg, end) : make_uint2(0u, 0u);
-    if (tid == 0 && tile == 0) im.counters[7] = (uint32_t)rec16;  // record format of this frame (read by the compositors)
-    if (n > cap) {  // cannot happen with the max_tile_list of gsaj_forward_num_rendered / a frame_scan-checked capacity
-      if (tid == 0) atomicOr(&im.counters[1], ERR_TILE_LIST);
-      return;
-    }
+    if (tid == 0 && tile == 0) im.counters[7] = (uint32_t)rec16;  // row format of this frame (read by the compositors)
+    // no pixel has reached any of the tile's instances yet (the reverse compositor sets the flags of the rows it writes).  The
+    // flags are indexed by emission slot, not by sorted position: the tiles' ranges merely tile [0, R)
+    for (uint32_t k = beg + tid; k < end; k += 256) reached[k] = 0;
   }
   if (n == 0) return;
-  int m = 2;
-  while (m < n) m <<= 1;
-  if (pass == 1 && 2 * m <= cap) return;  // pass 2's
-  if (pass == 2 && m > cap) return;       // pass 1's (here cap = half of pass 1's)
-  for (int i = tid; i < m; i += 256) keys[i] = i < n ? inst_key[beg + i] : ~0ull;
-  __syncthreads();
-#ifdef GSAJ_BLOCK_TRACE
-  tr_b = wall_clock64();
-#endif
-  // Bitonic network.  Comparators with stride <= 64 pair keys inside one aligned 128-key chunk, and a wave holds a
-  // chunk in REGISTERS (lane l: keys l and l + 64): stride 64 is in-lane, strides 32 / 16 use v_permlane32_swap /
-  // v_permlane16_swap, strides 8..1 DPP -- an LDS round trip per stage was the latency of this kernel.  So the
-  // first 28 stages (k = 2..128: every chunk sorted on its own) never touch LDS, and for k >= 256 only the
-  // strides >= 128 do (with workgroup barriers), followed by the seven chunk-local stages in registers again.
-  const int lane = tid & 63, wave = tid >> 6;
-#ifndef GSAJ_EXP_NOSORT  // (timing experiment: tools/ab_bench.sh)
-  for (int chunk = wave; chunk * 128 < m; chunk += 4) {
-    const int ia = chunk * 128 + lane, ib = ia + 64;
-    uint64_t A = ia < m ? keys[ia] : ~0ull, B = ib < m ? keys[ib] : ~0ull;
-    local_merges<2>(A, B, lane, ia, ib, m);
-    if (ia < m) keys[ia] = A;
-    if (ib < m) keys[ib] = B;
-  }
-  __syncthreads();
-  for (int k = 256; k <= m; k <<= 1) {
-    for (int j = k >> 1; j >= 128; j >>= 1) {
-      for (int i = tid; i < (m >> 1); i += 256) {
-        const int l = ((i & ~(j - 1)) << 1) | (i & (j - 1)), r = l + j;
-        const uint64_t a = keys[l], b = keys[r];
-        if ((a > b) == ((l & k) == 0)) {
-          keys[l] = b;
-          keys[r] = a;
-        }
-      }
-      __syncthreads();
-    }
-    for (int chunk = wave; chunk * 128 < m; chunk += 4) {
-      const int ia = chunk * 128 + lane, ib = ia + 64;
-      uint64_t A = keys[ia], B = keys[ib];
-      const bool asc = (ia & k) == 0;  // k >= 256: one direction for the whole chunk
-      merge_strides<64>(A, B, lane, asc, asc);
-      keys[ia] = A;
-      keys[ib] = B;
-    }
+  const uint64_t *sorted = keys;
+  if (n > cap) {
+    if (pass == 2) return;  // (pass 2 has half of pass 1's LDS: pass 1 took it)
+    sorted = sort_long_list(keys, cap, inst_key + beg, keys_b + beg, n, tid);
+  } else {
+    int m = 2;
+    while (m < n) m <<= 1;
+    if (pass == 1 && 2 * m <= cap) return;  // pass 2's
+    if (pass == 2 && m > cap) return;       // pass 1's (here cap = half of pass 1's)
+    for (int i = tid; i < m; i += 256) keys[i] = i < n ? inst_key[beg + i] : ~0ull;
     __syncthreads();
-  }
+#ifdef GSAJ_BLOCK_TRACE
+    tr_b = wall_clock64();
 #endif
+    lds_bitonic_sort(keys, m, tid);
+  }
 #ifdef GSAJ_BLOCK_TRACE
   tr_c = wall_clock64();
 #endif
-  const int ty = tile / gx, tx = tile - ty * gx;
-  for (int i = tid; i < n; i += 256) {
-    const uint64_t key = keys[i];
-    const uint32_t id = (uint32_t)key;
-    const uint32_t k = beg + (uint32_t)i;
-    point_list[k] = id;
-#ifdef GSAJ_EXP_NORECORDS
-    continue;
-#endif
-    const float4 a = g.splat[3 * (size_t)id + 0], bq = g.splat[3 * (size_t)id + 1], c = g.splat[3 * (size_t)id + 2];
-    const uint32_t rp = __float_as_uint(a.z);
-    const int x0 = (int)(rp & 1023u), y0 = (int)((rp >> 10) & 1023u), w = (int)(rp >> 20);
-    const uint32_t u = __float_as_uint(a.w) + (uint32_t)((ty - y0) * w + (tx - x0));
-    if (!rec16) {
-      records[(size_t)k * REC_F4 + 0] = make_float4(a.x, a.y, __uint_as_float((uint32_t)(key >> 32)), __uint_as_float(id));
-      records[(size_t)k * REC_F4 + 1] = bq;
-      records[(size_t)k * REC_F4 + 2] = make_float4(c.x, c.y, c.z, __uint_as_float(u));
-    } else {
-      records[(size_t)k * REC16_F4 + 0] = make_float4(a.x, a.y, __uint_as_float((uint32_t)(key >> 32)), __uint_as_float(u));
-      records[(size_t)k * REC16_F4 + 1] = make_float4(__uint_as_float(gsaj_pack_h2(bq.x, bq.y)), __uint_as_float(gsaj_pack_h2(bq.z, bq.w)),
-                                                      __uint_as_float(gsaj_pack_h2(c.x, c.y)), __uint_as_float(gsaj_pack_h2(c.z, 0.f)));
-    }
-  }
+  for (int i = tid; i < n; i += 256) point_list[beg + (uint32_t)i] = (uint32_t)sorted[i];
   GSAJ_TRACE_END(sort)
 #ifdef GSAJ_BLOCK_TRACE
   if ((threadIdx.x & 63) == 0) {
@@ -698,31 +778,6 @@ __global__ __launch_bounds__(256) void k_tile_sort_records(int gx, int gy, const
     t[3] = tr_c - tr_b;
   }
 #endif
-}
-
-// One (tile, depth) key + Gaussian id per touched tile, written at the Gaussian's slot range.
-// Also turns point_offsets into the global inclusive scan.
-__global__ __launch_bounds__(PRE_BLOCK) void k_emit_keys(int P, int gx, int gy, const int *__restrict__ radii, GeomWS g,
-                                                         const uint32_t *__restrict__ sticky, uint64_t *__restrict__ keys,
-                                                         uint32_t *__restrict__ vals) {
-  const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
-  if (idx >= P) return;
-  const uint32_t incl = g.block_sums[blockIdx.x] + g.point_offsets[idx];
-  g.point_offsets[idx] = incl;
-  const int r = radii[idx];
-  if (r > 0) {
-    uint32_t off = incl - g.tiles_touched[idx];
-    const float2 xy = g.means2D[idx];
-    int x0, y0, x1, y1;
-    tile_rect(xy.x, xy.y, r, gx, gy, gsaj_tile_band(sticky), x0, y0, x1, y1);
-    const uint32_t dbits = __float_as_uint(g.depths[idx]);
-    for (int y = y0; y < y1; y++)
-      for (int x = x0; x < x1; x++) {
-        keys[off] = ((uint64_t)(uint32_t)(y * gx + x) << 32) | dbits;
-        vals[off] = (uint32_t)idx;
-        off++;
-      }
-  }
 }
 
 __global__ __launch_bounds__(PRE_BLOCK) void k_mark_visible(int P, const float *__restrict__ means3D,
@@ -760,45 +815,34 @@ int launch_preprocess(const FwdParams &p, int *radii, int *n_touched, const Geom
   return GSAJ_OK;
 }
 
-int launch_tile_binning(int P, int R, int sort_cap, int rec16, int grid_x, int grid_y, const int *radii, const float *features,
-                        const GeomWS &g, const BinWS &b, const ImageWS &im, int views, ViewStrides vs, hipStream_t s) {
-  (void)R;
-  const int nblk = (P + PRE_BLOCK - 1) / PRE_BLOCK;
+int launch_tile_binning(int P, int sort_cap, int rec16, int grid_x, int grid_y, const GeomWS &g, const BinWS &b, const ImageWS &im,
+                        int views, ViewStrides vs, hipStream_t s) {
   {
     GsajProfScope ps(ST_SCATTER, s);
-    const int tiles = grid_x * grid_y;
-    const size_t lds = tiles <= LDS_TILES_MAX ? 2 * sizeof(uint32_t) * (size_t)tiles : 0;
-    hipLaunchKernelGGL(k_scatter_instances, dim3(nblk, views), dim3(PRE_BLOCK), lds, s, P, grid_x, grid_y, radii, g, im,
-                       b.keys_unsorted, vs);
+    const int ltiles = ((grid_y + SCAT_CLS - 1) / SCAT_CLS) * grid_x;
+    const size_t lds = ltiles <= SCAT_LDS_TILES ? 2 * sizeof(uint32_t) * (size_t)ltiles : 0;
+    const int per = PRE_BLOCK * SCAT_GPT;
+    hipLaunchKernelGGL(k_scatter_instances, dim3((unsigned)((P + per - 1) / per) * SCAT_CLS, views), dim3(PRE_BLOCK), lds, s, P, grid_x,
+                       grid_y, g, im, b.keys_unsorted, vs);
+    if (rec16)
+      hipLaunchKernelGGL(k_pack_splat16, dim3((P + 255) / 256, views), dim3(256), 0, s, P, g, im.counters, vs);
   }
   {
     GsajProfScope ps(ST_TILE_SORT, s);
     int cap = 128;
     while (cap < sort_cap && cap < SORT_CAP) cap <<= 1;
     if (sizeof(uint64_t) * (size_t)cap > 65536)  // lists of 8193 .. 16384 keys: more dynamic LDS than the 64 KB default limit
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_sort_records), hipFuncAttributeMaxDynamicSharedMemorySize,
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_sort), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(sizeof(uint64_t) * (size_t)cap));
     if (cap >= 4096) {
-      hipLaunchKernelGGL(k_tile_sort_records, dim3(grid_x * grid_y, views), dim3(256), sizeof(uint64_t) * (size_t)cap, s, grid_x, grid_y,
-                         radii, features, g, im, b.keys_unsorted, b.point_list, b.records, cap, 1, rec16, vs);
-      hipLaunchKernelGGL(k_tile_sort_records, dim3(grid_x * grid_y, views), dim3(256), sizeof(uint64_t) * (size_t)(cap / 2), s, grid_x,
-                         grid_y, radii, features, g, im, b.keys_unsorted, b.point_list, b.records, cap / 2, 2, rec16, vs);
+      hipLaunchKernelGGL(k_tile_sort, dim3(grid_x * grid_y, views), dim3(256), sizeof(uint64_t) * (size_t)cap, s, im, b.keys_unsorted,
+                         b.keys, b.point_list, b.reached, cap, 1, rec16, vs);
+      hipLaunchKernelGGL(k_tile_sort, dim3(grid_x * grid_y, views), dim3(256), sizeof(uint64_t) * (size_t)(cap / 2), s, im,
+                         b.keys_unsorted, b.keys, b.point_list, b.reached, cap / 2, 2, rec16, vs);
     } else {
-      hipLaunchKernelGGL(k_tile_sort_records, dim3(grid_x * grid_y, views), dim3(256), sizeof(uint64_t) * (size_t)cap, s, grid_x, grid_y,
-                         radii, features, g, im, b.keys_unsorted, b.point_list, b.records, cap, 0, rec16, vs);
+      hipLaunchKernelGGL(k_tile_sort, dim3(grid_x * grid_y, views), dim3(256), sizeof(uint64_t) * (size_t)cap, s, im, b.keys_unsorted,
+                         b.keys, b.point_list, b.reached, cap, 0, rec16, vs);
     }
-  }
-  GSAJ_HIP_CHECK(hipGetLastError());
-  return GSAJ_OK;
-}
-
-int launch_emit_keys(int P, int grid_x, int grid_y, const int *radii, const GeomWS &g, const BinWS &b, const ImageWS &im,
-                     hipStream_t s) {
-  const int nblk = (P + PRE_BLOCK - 1) / PRE_BLOCK;
-  {
-    GsajProfScope ps(ST_EMIT_KEYS, s);
-    hipLaunchKernelGGL(k_emit_keys, dim3(nblk), dim3(PRE_BLOCK), 0, s, P, grid_x, grid_y, radii, g, im.sticky,
-                       b.keys_unsorted, b.vals_unsorted);
   }
   GSAJ_HIP_CHECK(hipGetLastError());
   return GSAJ_OK;

@@ -28,7 +28,9 @@
 //  instance at the instance's emission slot.  The per-Gaussian kernel (gaussian_bwd.hip) sums a
 //  Gaussian's rows in a fixed order, so gradients are bit-reproducible run to run (the reference's
 //  float atomics are not).  Entries beyond the quadrant's / tile's furthest last-contributor are
-//  never visited; those beyond the tile's get a one-byte `reached = 0` flag instead of a zero row.
+//  never visited -- not even fetched: the list is a list of Gaussian ids, and the 48-byte rows they name
+//  (GeomWS.splat) are gathered per round of 48 entries, ids one round ahead.  Rows beyond the tile's furthest
+//  last contributor keep the one-byte `reached = 0` flag the tile sort gave them instead of a zero row.
 //  Workgroups take tiles longest list first (ImageWS.tile_order, written by the preprocess kernel's frame scan).
 #include "gsaj_common.h"
 #include "wave_reduce.h"
@@ -42,14 +44,16 @@
 GSAJ_TRACE_DEFINE(bwd)
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_render_bwd(int W, int H, int gx, ImageWS im,
-                                                    const float4 *__restrict__ records, const float *__restrict__ bg,
+                                                    const uint32_t *__restrict__ point_list, GeomWS g,
+                                                    const float *__restrict__ bg,
                                                     const float *__restrict__ dL_dpix,
                                                     const float *__restrict__ dL_dpix_depth,
                                                     float4 *__restrict__ inst_grad, uint8_t *__restrict__ reached, ViewStrides vs) {
   {  // batched launch: blockIdx.y = view
     const size_t view = blockIdx.y, HWv = (size_t)H * W;
     im = image_view(im, view * vs.image);
-    records = gsaj_shift(records, view * vs.bin);
+    point_list = gsaj_shift(point_list, view * vs.bin);
+    g = geom_view(g, view * vs.geom);
     inst_grad = gsaj_shift(inst_grad, view * vs.bin);
     reached = gsaj_shift(reached, view * vs.bin);
     dL_dpix += view * 3 * HWv;
@@ -110,23 +114,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
   const float p2_py = qy0 + (float)p2_row;
 
   uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(range.x + bmax));  // exclusive sorted position (workgroup-uniform: kept in scalar registers)
-  // entries [hi, range.y) were never reached by any pixel of the tile: their partials are zero.  Only a one-byte
-  // flag says so (opaque scenes leave most of a long list unreached: 48-byte zero rows would be most of the traffic)
-  const bool rec16 = counters[7] != 0u;  // fp16-storage records (gsaj_common.h)
-  for (uint32_t k = hi + tid; k < range.y; k += 256) reached[gsaj_record_emission_slot(records, (size_t)k, rec16)] = 0;
+  // entries [hi, range.y) were never reached by any pixel of the tile: their partials are zero, and their `reached` flags
+  // stay as the tile sort left them (opaque scenes leave most of a long list unreached: neither their ids nor their rows
+  // are ever fetched)
+  const bool rec16 = counters[7] != 0u;  // fp16-storage rows (gsaj_common.h)
+  uint32_t id_nxt = 0u;  // thread t < 48: Gaussian id of the NEXT round's entry t, requested a round ahead of its row
+  {
+    const uint32_t lo0 = (hi - range.x > BWD_ROUND) ? hi - BWD_ROUND : range.x;
+    if (hi > range.x && lo0 + (uint32_t)tid < hi) id_nxt = point_list[lo0 + tid];
+  }
 
   while (hi > range.x) {
     const uint32_t lo = (hi - range.x > BWD_ROUND) ? hi - BWD_ROUND : range.x;
     const int n = (int)(hi - lo);
     if (tid < n) {
+      const uint32_t id = id_nxt;
       float4 q0, q1, q2;
-      gsaj_load_record(records, nullptr, (size_t)(lo + tid), rec16, q0, q1, q2);
-      // the conic is staged PRE-SCALED for v_exp_f32 (gsaj_prescale_conic), like the forward's packed records: the per-entry loop
+      gsaj_load_row(g.splat, g.splat16, id, rec16, q0, q1, q2);
+      const uint32_t blk_first = g.block_sums[id / PRE_BLOCK];  // exclusive offset of the Gaussian's block (frame scan)
+      uint32_t x0, y0, w;
+      if (rec16) {
+        const uint4 sc = g.scat[id];
+        x0 = sc.y & 0xffffu, y0 = sc.z & 0xffffu, w = (sc.y >> 16) - x0;
+      } else {
+        const uint32_t rp = __float_as_uint(q2.w);
+        x0 = rp & 1023u, y0 = (rp >> 10) & 1023u, w = rp >> 20;
+      }
+      // emission slot: where this instance's partial gradients go (Gaussian-major, tiles of the rectangle in row order)
+      const uint32_t emit = blk_first + __float_as_uint(q0.w) + ((uint32_t)ty - y0) * w + ((uint32_t)tx - x0);
+      // the conic is staged PRE-SCALED for v_exp_f32 (gsaj_prescale_conic), like the forward's packed entries: the per-entry loop
       // below then spends no instructions on it; phase 2 (once per 8 entries) scales back
       const float3 kq = gsaj_prescale_conic(q1.x, q1.y, q1.z);
-      rec[tid * REC_F4 + 0] = q0;
+      rec[tid * REC_F4 + 0] = make_float4(q0.x, q0.y, q0.z, __uint_as_float(id));
       rec[tid * REC_F4 + 1] = make_float4(kq.x, kq.y, kq.z, q1.w);
-      rec[tid * REC_F4 + 2] = q2;
+      rec[tid * REC_F4 + 2] = make_float4(q2.x, q2.y, q2.z, __uint_as_float(emit));
+    }
+    if (lo > range.x) {  // the next round's ids
+      const uint32_t lo2 = (lo - range.x > BWD_ROUND) ? lo - BWD_ROUND : range.x;
+      if (lo2 + (uint32_t)tid < lo) id_nxt = point_list[lo2 + tid];
     }
     {
       float4 *z = reinterpret_cast<float4 *>(acc);
@@ -280,13 +305,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
   GSAJ_TRACE_END(bwd)
 }
 
-int launch_render_backward(int R, int W, int H, int grid_x, int grid_y, const float *bg, const BinWS &b,
+int launch_render_backward(int R, int W, int H, int grid_x, int grid_y, const float *bg, const GeomWS &g, const BinWS &b,
                            const ImageWS &im, const float *dL_dpix, const float *dL_dpix_depth, int views, ViewStrides vs,
                            hipStream_t s) {
   if (R <= 0) return GSAJ_OK;  // (async callers pass the arena capacity as R)
   {
     GsajProfScope ps(ST_RENDER_BWD, s);
-    hipLaunchKernelGGL(k_render_bwd, dim3(grid_x * grid_y, views), dim3(256), 0, s, W, H, grid_x, im, b.records, bg, dL_dpix,
+    hipLaunchKernelGGL(k_render_bwd, dim3(grid_x * grid_y, views), dim3(256), 0, s, W, H, grid_x, im, b.point_list, g, bg, dL_dpix,
                        dL_dpix_depth, b.inst_grad, b.reached, vs);
   }
   GSAJ_HIP_CHECK(hipGetLastError());

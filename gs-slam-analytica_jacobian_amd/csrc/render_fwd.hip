@@ -4,10 +4,11 @@
 // alpha < 1/255 skipped, stop before T(1-alpha) < 1e-4, n_touched counts T(1-alpha) > 0.5.
 //
 // MI355X mapping: one 256-thread workgroup per 16x16 tile = four wave64s, each owning an 8x8 pixel quadrant (one
-// pixel per lane) and walking the tile list on its own -- no workgroup barrier in the loop.  Per 64 sorted 48-byte
-// records: coalesced fetch (the next chunk is requested before the current one is composited), a lane-parallel test
-// of entry l against the quadrant box (wave_reduce.h), and the survivors PACKED in list order into the wave's LDS area
-// with the conic pre-scaled for v_exp_f32.  The entry loop is straight-line, two entries per step, the next step's
+// pixel per lane) and walking the tile list on its own -- no workgroup barrier in the loop.  Per 64 sorted list
+// entries: lane l takes entry l -- its Gaussian id from point_list (coalesced; requested TWO chunks ahead) and that
+// Gaussian's 48-byte row gathered from GeomWS.splat (requested ONE chunk ahead; the rows of a frame live in L2) -- a
+// lane-parallel test of the entry against the quadrant box (wave_reduce.h), and the survivors PACKED in list order into
+// the wave's LDS area with the conic pre-scaled for v_exp_f32.  The entry loop is straight-line, two entries per step, the next step's
 // records requested from LDS before this step's arithmetic; a pixel that skips an entry runs the same arithmetic with
 // weight 0 instead of branching.  Early-outs are wave-level ballots (a quadrant whose 64 pixels have all saturated
 // stops), not the reference's block-wide votes.  n_touched: lane l counts packed entry l, only while some pixel of the
@@ -32,14 +33,16 @@
 GSAJ_TRACE_DEFINE(fwd)
 
 __global__ __launch_bounds__(GSAJ_FWD_THREADS) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_render_fwd(int W, int H, int gx, int tiles, int P, ImageWS im,
-                                                    const float4 *__restrict__ records, const float *__restrict__ bg,
+                                                    const float4 *__restrict__ splat, const float4 *__restrict__ splat16,
+                                                    const float *__restrict__ bg,
                                                     float *__restrict__ out_color, float *__restrict__ out_depth,
                                                     float *__restrict__ out_opacity, int *__restrict__ n_touched,
                                                     const uint32_t *__restrict__ point_list, ViewStrides vs) {
   {  // batched launch: blockIdx.y = view
     const size_t view = blockIdx.y, HWv = (size_t)H * W;
     im = image_view(im, view * vs.image);
-    records = gsaj_shift(records, view * vs.bin);
+    splat = gsaj_shift(splat, view * vs.geom);
+    splat16 = gsaj_shift(splat16, view * vs.geom);
     point_list = gsaj_shift(point_list, view * vs.bin);
     out_color += view * 3 * HWv;
     out_depth += view * HWv;
@@ -52,7 +55,7 @@ __global__ __launch_bounds__(GSAJ_FWD_THREADS) __attribute__((amdgpu_waves_per_e
   uint32_t *__restrict__ counters = im.counters;
   // Each wave (one 8x8 quadrant) walks the tile list on its own: private 64-record staging area, no
   // workgroup barrier anywhere, so a quadrant never waits for a slower neighbour.  The four waves of a
-  // tile read the same records; the repeats are served by L1/L2.
+  // tile gather the same rows; the repeats are served by L1/L2.
   __shared__ float4 rec_all[FWD_WAVES * (FWD_CHUNK + FWD_PAD) * REC_F4];
   if (counters[4]) return;  // aborted async frame
   GSAJ_TRACE_BEGIN(fwd)
@@ -105,18 +108,27 @@ __global__ __launch_bounds__(GSAJ_FWD_THREADS) __attribute__((amdgpu_waves_per_e
   };
 
   if (__builtin_amdgcn_ballot_w64(!done) != 0ull && range.x < range.y) {
-    // the next chunk's records are requested from HBM/L2 before the current chunk is composited
+    // two loads in a row per entry (id, then the row it names): ids are requested two chunks ahead and rows one chunk ahead,
+    // so that neither round trip is waited for behind the other
     float4 q0, q1, q2;
-    const bool rec16 = counters[7] != 0u;  // fp16-storage records (gsaj_common.h)
-    auto fetch = [&](uint32_t base) {
-      if (base + (uint32_t)lane < range.y) gsaj_load_record(records, point_list, (size_t)(base + lane), rec16, q0, q1, q2);
+    uint32_t id_cur = 0u, id_nxt = 0u;
+    const bool rec16 = counters[7] != 0u;  // fp16-storage rows (gsaj_common.h)
+    auto fetch_id = [&](uint32_t base) {
+      if (base + (uint32_t)lane < range.y) id_nxt = point_list[base + lane];
     };
-    fetch(range.x);
+    auto fetch_row = [&](uint32_t base) {  // (of the chunk whose ids fetch_id requested last)
+      id_cur = id_nxt;
+      if (base + (uint32_t)lane < range.y) gsaj_load_row(splat, splat16, id_nxt, rec16, q0, q1, q2);
+    };
+    fetch_id(range.x);
+    fetch_row(range.x);
+    fetch_id(range.x + FWD_CHUNK);
     for (uint32_t base = range.x; base < range.y; base += FWD_CHUNK) {
       const int m = min((uint32_t)FWD_CHUNK, range.y - base);
-      // stage: lane l holds record base+l and tests it against the quadrant; the records the quadrant can see
+      // stage: lane l holds the row of entry base+l and tests it against the quadrant; the entries the quadrant can see
       // are packed to the front of the wave's LDS area in list order
       bool rel = false;
+      const uint32_t id_here = id_cur;
       if (lane < m) rel = quadrant_relevant(q0.x, q0.y, q1.x, q1.y, q1.z, q1.w, qx0, qy0);
       const unsigned long long todo = __builtin_amdgcn_ballot_w64(rel);
       const int nrel = __popcll(todo);
@@ -124,12 +136,13 @@ __global__ __launch_bounds__(GSAJ_FWD_THREADS) __attribute__((amdgpu_waves_per_e
       if (rel) {
         const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(todo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)todo, 0u));
         const float3 k = gsaj_prescale_conic(q1.x, q1.y, q1.z);
-        rec[slot * REC_F4 + 0] = q0;
+        rec[slot * REC_F4 + 0] = make_float4(q0.x, q0.y, q0.z, __uint_as_float(id_here));
         rec[slot * REC_F4 + 1] = make_float4(k.x, k.y, k.z, q1.w);
         rec[slot * REC_F4 + 2] = make_float4(q2.x, q2.y, q2.z, __uint_as_float(base - range.x + (uint32_t)lane + 1u));
       }
       if (lane < FWD_PAD * REC_F4) rec[nrel * REC_F4 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);  // inert sentinels (opacity 0)
-      fetch(base + FWD_CHUNK);
+      fetch_row(base + FWD_CHUNK);
+      fetch_id(base + 2 * FWD_CHUNK);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -194,14 +207,14 @@ __global__ __launch_bounds__(GSAJ_FWD_THREADS) __attribute__((amdgpu_waves_per_e
   GSAJ_TRACE_END(fwd)
 }
 
-int launch_render_forward(int P, int W, int H, int grid_x, int grid_y, const float *bg, const BinWS &b, const ImageWS &im,
-                          float *out_color, float *out_depth, float *out_opacity, int *n_touched, int views, ViewStrides vs,
-                          hipStream_t s) {
+int launch_render_forward(int P, int W, int H, int grid_x, int grid_y, const float *bg, const GeomWS &g, const BinWS &b,
+                          const ImageWS &im, float *out_color, float *out_depth, float *out_opacity, int *n_touched, int views,
+                          ViewStrides vs, hipStream_t s) {
   {
     GsajProfScope ps(ST_RENDER_FWD, s);
     const int tiles = grid_x * grid_y;
     const unsigned nblk = FWD_WAVES == 1 ? (unsigned)((tiles + 7) / 8) * 32u : (unsigned)tiles;
-    hipLaunchKernelGGL(k_render_fwd, dim3(nblk, views), dim3(GSAJ_FWD_THREADS), 0, s, W, H, grid_x, tiles, P, im, b.records, bg, out_color,
+    hipLaunchKernelGGL(k_render_fwd, dim3(nblk, views), dim3(GSAJ_FWD_THREADS), 0, s, W, H, grid_x, tiles, P, im, g.splat, g.splat16, bg, out_color,
                        out_depth, out_opacity, n_touched, b.point_list, vs);
   }
   GSAJ_HIP_CHECK(hipGetLastError());

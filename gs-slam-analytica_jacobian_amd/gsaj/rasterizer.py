@@ -12,8 +12,10 @@ import torch
 from . import _lib
 
 _F32 = torch.float32
-FORCE_GLOBAL_SORT = bool(int(__import__("os").environ.get("GSAJ_FORCE_GLOBAL_SORT", "0")))  # tests flip this (or set the variable) to exercise the global radix-sort binning path
-SORT_CAP = 16384  # longest tile list the per-tile LDS sort handles (csrc/gsaj_common.h)
+# tests flip this (or set the variable) to push every tile list longer than 128 entries through the chunk + merge path of the
+# tile sort (the path a list longer than the LDS capacity takes)
+FORCE_CHUNKED_SORT = bool(int(__import__("os").environ.get("GSAJ_FORCE_CHUNKED_SORT", "0")))
+SORT_CAP = 16384  # longest tile list the per-tile sort handles in ONE LDS pass (csrc/gsaj_common.h); longer: chunks + merge passes
 
 
 def _ptr(t):
@@ -95,7 +97,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         nbytes = lib.gsaj_binning_workspace_bytes(R)
         binning = torch.empty(nbytes, **byte)
         _lib.check(lib.gsaj_forward_render(
-            P, R, -1 if FORCE_GLOBAL_SORT else mt.value, W, H, _ptr(background), _ptr(colors), radii.data_ptr(), geom.data_ptr(), binning.data_ptr(), nbytes,
+            P, R, -1 if FORCE_CHUNKED_SORT else mt.value, W, H, _ptr(background), _ptr(colors), radii.data_ptr(), geom.data_ptr(), binning.data_ptr(), nbytes,
             img.data_ptr(), out_color.data_ptr(), out_depth.data_ptr(), out_opacity.data_ptr(), n_touched.data_ptr(),
             _fwd_flags(record_bits), st), "gsaj_forward_render")
         if debug:
@@ -269,7 +271,8 @@ class FrameContext:
         self.binning = torch.empty(0, **byte)
         self.R = 0
         self.capacity = 0  # > 0 once an arena has been sized: enables forward(sync=False)
-        self.tile_list_capacity = 0  # longest tile list asynchronous frames may contain (0: the maximum, 16384)
+        self.tile_list_capacity = 0  # tile-list length the LDS sort of asynchronous frames is sized for (0: the maximum, 16384);
+                                     # a longer list is sorted in chunks + merge passes (slower, never wrong)
         # per-Gaussian parameter gradients live in ONE flat bucket (field-major) so that a multi-GPU
         # mapping step can all-reduce it with a single collective (gsaj.keyframe_shard); `grad_slots`
         # buckets let the collective of step i overlap the kernels of step i+1
@@ -316,8 +319,8 @@ class FrameContext:
                                                       ctypes.byref(R), ctypes.byref(mt)), "gsaj_forward_num_rendered")
         self.true_R = R.value
         if n.value:
-            raise _lib.GsajError("%d asynchronous forward(s) were aborted on the device (binning arena too small or a tile list "
-                                 "longer than tile_list_capacity=%d); run forward(sync=True) to re-size" % (n.value, self.tile_list_capacity))
+            raise _lib.GsajError("%d asynchronous forward(s) were aborted on the device (binning arena too small for the frame's "
+                                 "instances); run forward(sync=True) to re-size" % n.value)
         return R.value, mt.value
 
     def forward(self, bg, means3D, opacities, viewmatrix, projmatrix, campos, tanfovx, tanfovy, sh_degree=0, shs=None,
@@ -353,13 +356,12 @@ class FrameContext:
         self.R, self.max_tile_list = R.value, mt.value
         # asynchronous frames get an LDS sort sized for the longest tile list seen so far + 10 % (the launcher rounds up to a power
         # of two, which is what the bitonic network pads to anyway; more LDS than that only costs resident workgroups: 2x the
-        # longest list made cfg5's sort 2.2x slower).  A longer list aborts the frame on the device, exactly like an arena
-        # overflow: status() raises, forward(sync=True) recovers
+        # longest list made cfg5's sort 2.2x slower).  A longer list is still sorted -- in LDS-sized chunks and merge passes
         self.tile_list_capacity = min(SORT_CAP, max(self.tile_list_capacity, int(1.1 * self.max_tile_list) + 1, 256))
         self._ensure_binning(self.R)
         self.true_R = self.R
         _lib.check(lib.gsaj_forward_render(
-            self.P, self.R, -1 if FORCE_GLOBAL_SORT else self.max_tile_list, self.W, self.H, _ptr(bg), _ptr(colors_precomp), self.radii.data_ptr(), self.geom.data_ptr(),
+            self.P, self.R, -1 if FORCE_CHUNKED_SORT else self.max_tile_list, self.W, self.H, _ptr(bg), _ptr(colors_precomp), self.radii.data_ptr(), self.geom.data_ptr(),
             self.binning.data_ptr(), self.binning.numel(), self.img.data_ptr(), self.color.data_ptr(),
             self.depth.data_ptr(), self.opacity.data_ptr(), self.n_touched.data_ptr(), self.flags, st), "gsaj_forward_render")
         return self.R
@@ -470,6 +472,16 @@ class BatchContext:
             out.append((R.value, mt.value, rc == -3))
         return out
 
+    def clear_aborts(self):
+        """Blocking: read and clear every view's count of aborted asynchronous forwards; returns their sum."""
+        total, st = 0, _stream(self.dev)
+        for v in range(self.K):
+            n = ctypes.c_int(0)
+            _lib.check(self.lib.gsaj_forward_aborted_count(self.W, self.H, self.img.data_ptr() + v * self.img_stride, st, ctypes.byref(n)),
+                       "gsaj_forward_aborted_count")
+            total += n.value
+        return total
+
     def _fork(self):
         """side streams wait for everything the caller's stream has enqueued so far (inputs, the previous step's results)"""
         cur = torch.cuda.current_stream(self.dev)
@@ -504,7 +516,8 @@ class BatchContext:
                 colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, scale_modifier=1.0, sync=True):
         """viewmatrices / projmatrices [K,4,4] (the rasteriser's transposed matrices), campos [K,3].
         sync=False: no host round trip (arena from an earlier synchronous call; overflowing views abort on the device).
-        sync=True: the K instance counts are read back; if a view did not fit, the arena grows and the batch is re-run."""
+        sync=True: the K instance counts are read back; if a view did not fit, the arena grows and the batch is re-run (tile bands
+    set with set_tile_band stay in force: only the abort counters are cleared)."""
         a = (bg, means3D, opacities, viewmatrices, projmatrices, campos, tanfovx, tanfovy, sh_degree, shs, colors_precomp, scales,
              rotations, cov3D_precomp, scale_modifier)
         if self.capacity == 0:
@@ -516,11 +529,11 @@ class BatchContext:
         if any(ab for _, _, ab in st):
             self._size(int(1.5 * max(r for r, _, _ in st)) + 1024)
             self.tile_list_capacity = 0  # the maximum (16384) until the lists are known
-            self.img.zero_()
+            self.clear_aborts()          # (NOT img.zero_(): the image workspaces also hold the views' tile bands)
             self._launch(*a)
             st = self.status()
             if any(ab for _, _, ab in st):
-                raise _lib.GsajError("a view needs a tile list longer than the LDS sort handles (16384): use the single-view entry points")
+                raise _lib.GsajError("the batch was aborted again after re-sizing the arena to %d instances per view: %r" % (self.capacity, st))
         self.tile_list_capacity = min(SORT_CAP, max(self.tile_list_capacity, int(1.1 * max(m for _, m, _ in st)) + 1, 256))
         return st
 

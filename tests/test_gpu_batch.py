@@ -160,6 +160,43 @@ def test_batch_aborted_view_contributes_nothing_and_is_reported():
             assert float(g2["tau_all"][k].abs().max()) == 0.0
 
 
+def test_batch_tile_lists_longer_than_the_lds_sort_are_sorted_not_dropped():
+    """A view whose tile lists exceed the LDS sort capacity (> 16384 entries) goes through the batched, host-sync-free path like any
+    other (the reference sorts any length, rasterizer_impl.cu:353-368): point_list / ranges bit for bit the oracle's, images and
+    gradients equal to the single-view path, nothing aborted -- with the LDS sized for the maximum and for a stale, short capacity."""
+    import torch
+    from gsaj import rasterizer as C
+    from oracle import oracle as orc
+
+    K = 2
+    cam = hp.small_camera(32, 32, f=30.0, orthonormal=True)
+    sc = syn.make_scene(18000, 9, cam, z_range=(1.0, 3.0), log_scale_range=(np.log(0.2), np.log(0.5)), sh_coeffs=1,
+                        opacity_range=(0.004, 0.02), margin=-0.1)
+    cams = [cam, cam]
+    bc, g, st, singles, _ = _run(K, cams, sc, 0)
+    assert max(m for _, m, _ in st) > C.SORT_CAP and not any(ab for _, _, ab in st)
+    _compare(bc, g, st, singles, False)
+    (ref, ost), kw = hp.oracle_forward(cam, sc, 0)
+    P = sc["means3D"].shape[0]
+    for cap in (0, 700):  # 0: the maximum; 700: an LDS capacity (1024 keys) far below the lists
+        if cap:
+            bc.tile_list_capacity = cap
+            dev = torch.device("cuda:0")
+            t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)  # noqa: E731
+            bc.forward(t(np.array([0.1, 0.2, 0.3])), t(sc["means3D"]), t(sc["opacities"]), t(np.stack([c["viewmatrix"] for c in cams])),
+                       t(np.stack([c["projmatrix"] for c in cams])), t(np.stack([c["campos"] for c in cams])), cam["tanfovx"], cam["tanfovy"],
+                       sh_degree=0, shs=t(sc["shs"]), scales=t(sc["scales"]), rotations=t(sc["rotations"]), sync=False)
+            assert not any(ab for _, _, ab in bc.status())
+        for v in range(K):
+            blk = lambda buf, stride: buf[v * stride:(v + 1) * stride]  # noqa: E731
+            # (a view's binning block is carved for the arena capacity, not for its own instance count)
+            dbg = C.debug_export(P, bc.capacity, cam["W"], cam["H"], blk(bc.geom, bc.geom_stride), blk(bc.binning, bc.bin_stride),
+                                 blk(bc.img, bc.img_stride))
+            np.testing.assert_array_equal(dbg["point_list"].cpu().numpy().astype(np.uint32)[:ost["num_rendered"]], ost["point_list"])
+            np.testing.assert_array_equal(dbg["ranges"].cpu().numpy(), ost["ranges"])
+            assert torch.equal(bc.color[v], singles[v][0].color)
+
+
 def test_bucket_gradients_through_the_activations_equal_autograd_on_the_drop_in():
     """GaussianModel.assign_bucket_gradients: the batched backward's bucket (gradients w.r.t. the ACTIVATED scales / rotations /
     opacities / SH the rasteriser is fed) chained in closed form through the reference model's activations must leave in .grad of

@@ -118,13 +118,13 @@ def test_bands_async_forward_precomp_and_fp16_records():
     _check_bands(cam, sc, deg, tbs.uniform_bands(cam["H"], 2), record_bits=16, tag="band/rec16")
 
 
-def test_bands_global_sort_fallback(monkeypatch):
-    """The rocPRIM fallback for long tile lists (k_emit_keys / k_ranges_records) clips to the band as well."""
+def test_bands_chunked_sort(monkeypatch):
+    """Tile lists longer than the LDS sort capacity (chunks + merge passes) under a band."""
     from gsaj import rasterizer as C
 
-    monkeypatch.setattr(C, "FORCE_GLOBAL_SORT", True)
+    monkeypatch.setattr(C, "FORCE_CHUNKED_SORT", True)
     cam, sc, deg = hp.make("p2000_160x120")
-    _check_bands(cam, sc, deg, [(0, 3), (3, 8)], tag="band/global_sort")
+    _check_bands(cam, sc, deg, [(0, 3), (3, 8)], tag="band/chunked_sort")
 
 
 def test_full_size_cfg2_bands_balanced_by_work_hold_the_oracle_tolerances():

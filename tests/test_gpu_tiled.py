@@ -223,28 +223,30 @@ def test_dL_dtau_matches_finite_differences(torch_cuda):
 
 
 @pytest.mark.parametrize("mode", ["forced", "long_lists_in_lds", "oversized_tile"])
-def test_global_sort_fallback_path(torch_cuda, mode):
-    """Binning has two paths: per-tile LDS sort (lists <= 16384 entries: up to 128 KB of LDS) and the global radix sort of
-    (tile, depth) keys.  Both must give the oracle's order bit for bit -- also for lists of ~6000 entries, which use more
-    dynamic LDS than the 64 KB default limit, and for lists beyond the LDS capacity."""
+def test_long_tile_lists(torch_cuda, mode):
+    """The tile sort has two paths: one LDS pass (lists up to the capacity the launch was sized for, at most 16384 entries = 128 KB
+    of LDS) and LDS-sized chunks + merge passes inside the tile's workgroup for longer lists (the reference's global radix sort
+    takes any length, rasterizer_impl.cu:353-368).  Both must give the oracle's order bit for bit -- "forced": every list longer
+    than 128 entries through chunks of 128; lists of ~6000 entries (more dynamic LDS than the 64 KB default limit); lists
+    beyond the LDS capacity."""
     from gsaj import rasterizer as C
     from gsaj import synthetic as syn
     from oracle import oracle as orc
 
     if mode == "forced":
         cam, sc, deg = hp.make("p2000_160x120")
-    else:  # 6000 / 18000 Gaussians on a 32x32 image: every tile list has ~6000 (LDS, > 64 KB) / > 16384 (fallback) entries
+    else:  # 6000 / 18000 Gaussians on a 32x32 image: every tile list has ~6000 (LDS, > 64 KB) / > 16384 (chunks + merge) entries
         n = 6000 if mode == "long_lists_in_lds" else 18000
         cam = hp.small_camera(32, 32, f=30.0, orthonormal=True)
         sc = syn.make_scene(n, 9, cam, z_range=(1.0, 3.0), log_scale_range=(np.log(0.2), np.log(0.5)), sh_coeffs=1,
                             opacity_range=(0.01, 0.05) if n == 6000 else (0.004, 0.02), margin=-0.1)
         deg = 0
     (ref, st), kw = hp.oracle_forward(cam, sc, deg)
-    C.FORCE_GLOBAL_SORT = mode == "forced"
+    C.FORCE_CHUNKED_SORT = mode == "forced"
     try:
         out, args = hp.gpu_forward(cam, sc, deg, kw=kw)
     finally:
-        C.FORCE_GLOBAL_SORT = False
+        C.FORCE_CHUNKED_SORT = False
     R, color, radii, geom, binning, img, depth, opacity, n_touched = out
     longest = (st["ranges"][:, 1] - st["ranges"][:, 0]).max()
     if mode == "long_lists_in_lds":
@@ -256,7 +258,7 @@ def test_global_sort_fallback_path(torch_cuda, mode):
     np.testing.assert_array_equal(dbg["ranges"], st["ranges"])
     hp.assert_image_close(color.cpu().numpy(), ref["color"], IMG_TOL, st=st)
     dLc, dLd = hp.seeds(cam, seed=3)
-    g, gref = hp.check_backward(cam, deg, out, args, st, dLc, dLd, "global_sort/" + mode)
+    g, gref = hp.check_backward(cam, deg, out, args, st, dLc, dLd, "long_lists/" + mode)
 
 
 def test_async_forward_matches_sync_and_reports_overflow(torch_cuda):
@@ -294,17 +296,20 @@ def test_async_forward_matches_sync_and_reports_overflow(torch_cuda):
     ctx.forward(**args, sync=False)
     with pytest.raises(_lib.GsajError, match="too small|aborted"):
         ctx.status()
-    # same for a tile list longer than the LDS sort was sized for
+    # a tile list longer than the LDS sort was sized for is NOT an abort: it is sorted in chunks + merge passes, same bits
     ctx2 = FrameContext(P, cam["W"], cam["H"], M, dev)
     ctx2.forward(**args, sync=True)
     longest = ctx2.status()[1]
     assert ctx2.tile_list_capacity >= longest
     ctx2.forward(**args, sync=False)
     assert torch.equal(ctx2.color, ref[0])
-    ctx2.tile_list_capacity = max(1, longest // 2)
-    ctx2.forward(**args, sync=False)
-    with pytest.raises(_lib.GsajError, match="tile list|aborted"):
-        ctx2.status()
+    for cap in (max(1, longest // 2), 1):
+        ctx2.tile_list_capacity = cap
+        ctx2.forward(**args, sync=False)
+        g2 = ctx2.backward(**bargs)
+        assert ctx2.status()[0] == R_true
+        for a, b in zip(ref, [ctx2.color, ctx2.depth, ctx2.n_touched, ctx2.bucket, g2["tau_sum"]]):
+            assert torch.equal(a, b)
 
 
 def test_mark_visible_matches_oracle(torch_cuda):
