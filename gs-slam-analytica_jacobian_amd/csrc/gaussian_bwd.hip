@@ -35,9 +35,10 @@ __device__ __forceinline__ float3 dnormvdv(float3 v, float3 dv) {
 // SH backward.  `sh` holds this Gaussian's coefficients [M][3]; dL/dsh goes to `dL_dsh` (zeros above the active degree).
 // dL_dsh may alias sh (the single-view kernel works in place): within a band every coefficient is read before the band's
 // gradients overwrite it.  Returns dL/dmean through the view direction.
-// WEIGHTS: dL_dsh receives only the M basis weights w_k of this view direction (dL/dsh[k][ch] = w_k * g[ch], g = the colour
-// gradient masked by the clamp flags): the batched kernel sums w_k g[ch] over views itself.
-template <bool WEIGHTS>
+// MODE 0: dL_dsh[k][ch] = w_k g[ch] (w_k = the basis weights of this view direction, g = the colour gradient masked by the clamp
+// flags); MODE 1: dL_dsh[k] = w_k only (the batched path sums w_k g[ch] over views itself; nothing is written above the active
+// degree); MODE 2: dL_dsh[k][ch] += w_k g[ch].
+template <int MODE>
 __device__ __forceinline__ float3 sh_backward(int deg, int M, float3 pos, float3 campos, const float *sh, float *dL_dsh,
                                               const uint8_t *__restrict__ clamped, float3 gcol) {
   const float3 dorig = make_float3(pos.x - campos.x, pos.y - campos.y, pos.z - campos.z);
@@ -49,8 +50,12 @@ __device__ __forceinline__ float3 sh_backward(int deg, int M, float3 pos, float3
 #define OUT(k, w)                                                                  \
   {                                                                                \
     const float _w = (w);                                                          \
-    if (WEIGHTS) {                                                                 \
+    if (MODE == 1) {                                                               \
       dL_dsh[(k)] = _w;                                                            \
+    } else if (MODE == 2) {                                                        \
+      dL_dsh[(k) * 3 + 0] += _w * g[0];                                            \
+      dL_dsh[(k) * 3 + 1] += _w * g[1];                                            \
+      dL_dsh[(k) * 3 + 2] += _w * g[2];                                            \
     } else {                                                                       \
       dL_dsh[(k) * 3 + 0] = _w * g[0];                                             \
       dL_dsh[(k) * 3 + 1] = _w * g[1];                                             \
@@ -97,7 +102,7 @@ __device__ __forceinline__ float3 sh_backward(int deg, int M, float3 pos, float3
   }
 #undef SH
 #undef OUT
-  if (!WEIGHTS)
+  if (MODE == 0)
     for (int k = (deg + 1) * (deg + 1) * 3; k < 3 * M; k++) dL_dsh[k] = 0.f;  // coefficients above the active degree
   const float3 ddir = make_float3(dx[0] * g[0] + dx[1] * g[1] + dx[2] * g[2], dy[0] * g[0] + dy[1] * g[1] + dy[2] * g[2],
                                   dz[0] * g[0] + dz[1] * g[1] + dz[2] * g[2]);
@@ -146,10 +151,10 @@ struct GaussianGrads {
   float4 rot;
   float cov[6];
 };
-template <bool SH_WEIGHTS>
-__device__ __forceinline__ void gaussian_chain(const BwdParams &p, float3 mean, const float (&c6)[6], float3 sc, float4 q,
-                                               const uint8_t (&cl)[3], float4 s0, float4 s1, float4 s2, const float *sh_row,
-                                               float *dsh_row, bool want_scale_rot, GaussianGrads &o, float (&tau)[6]) {
+// gaussian_chain_geom: everything but the colour -> SH / view-direction part and cov3D -> (scale, rotation): o.gm and tau
+// lack the view-direction term (sh_backward's return value: gm += d, tau[0..2] -= d), o.scale / o.rot are not set.
+__device__ __forceinline__ void gaussian_chain_geom(const BwdParams &p, float3 mean, const float (&c6)[6], float4 s0, float4 s1, float4 s2,
+                                                    GaussianGrads &o, float (&tau)[6]) {
   const float g2x = s0.x, g2y = s0.y;           // dL/dmean2D (NDC-scaled)
   const float gcx = s0.z, gcy = s0.w, gcz = s1.x;  // dL/dconic a, b, c
   const float gop = s1.y;
@@ -260,16 +265,21 @@ __device__ __forceinline__ void gaussian_chain(const BwdParams &p, float3 mean, 
   tau[2] += gz;
   tau[3] += gz * pC.y;
   tau[4] += gz * -pC.x;
+  o.m2x = g2x; o.m2y = g2y; o.ca = gcx; o.cb = gcy; o.cc = gcz; o.op = gop; o.col = gcol; o.dz = gz; o.gm = gm;
+}
+__device__ __forceinline__ void gaussian_chain(const BwdParams &p, float3 mean, const float (&c6)[6], float3 sc, float4 q,
+                                               const uint8_t (&cl)[3], float4 s0, float4 s1, float4 s2, const float *sh_row,
+                                               float *dsh_row, bool want_scale_rot, GaussianGrads &o, float (&tau)[6]) {
+  gaussian_chain_geom(p, mean, c6, s0, s1, s2, o, tau);
   // ---- 5. colour -> SH, view direction -> mean3D, tau ----
   if (p.shs) {
     const float3 cam = make_float3(p.campos[0], p.campos[1], p.campos[2]);
-    const float3 dmean = sh_backward<SH_WEIGHTS>(p.D, p.M, mean, cam, sh_row, dsh_row, cl, gcol);
-    gm.x += dmean.x; gm.y += dmean.y; gm.z += dmean.z;
+    const float3 dmean = sh_backward<0>(p.D, p.M, mean, cam, sh_row, dsh_row, cl, o.col);
+    o.gm.x += dmean.x; o.gm.y += dmean.y; o.gm.z += dmean.z;
     tau[0] -= dmean.x; tau[1] -= dmean.y; tau[2] -= dmean.z;
   }
-  o.m2x = g2x; o.m2y = g2y; o.ca = gcx; o.cb = gcy; o.cc = gcz; o.op = gop; o.col = gcol; o.dz = gz; o.gm = gm;
   // ---- 6. cov3D -> scale, rotation ----
-  if (p.scales && want_scale_rot) cov3d_backward(gcov, sc, q, p.scale_modifier, o.scale, o.rot);
+  if (p.scales && want_scale_rot) cov3d_backward(o.cov, sc, q, p.scale_modifier, o.scale, o.rot);
 }
 
 // Four workgroups' dL/dtau partials (8 floats each, 6 used) as seen by ANOTHER workgroup after the ticket: 16-byte loads that
@@ -433,8 +443,8 @@ __global__ __launch_bounds__(GB_BLOCK) void k_gaussian_bwd(BwdParams p, GeomWS g
 #pragma unroll
   for (int k = 0; k < 6; k++) o.cov[k] = 0.f;
   if (vis)
-    gaussian_chain<false>(p, mean, c6, sc, q, cl, s0, s1, s2, sh_io + tid * shs_stride, sh_io + tid * shs_stride,
-                          p.dL_dscale != nullptr, o, tau);
+    gaussian_chain(p, mean, c6, sc, q, cl, s0, s1, s2, sh_io + tid * shs_stride, sh_io + tid * shs_stride,
+                   p.dL_dscale != nullptr, o, tau);
   TRM(2)
   // ---- 7. wave partial of dL/dtau (fixed butterfly) ----
 #pragma unroll
@@ -537,16 +547,11 @@ int launch_gaussian_backward(const BwdParams &p, const GeomWS &g, const BinWS &b
 // ---- batched: K views of one map, per-Gaussian parameter gradients summed over the views IN-KERNEL --------------------
 // A mapping window renders every keyframe against the same Gaussians and back-propagates once, so the per-Gaussian
 // gradients accumulate over keyframes while every keyframe keeps its own dL/dtau (reference utils/slam_backend.py:168-232).
-// Two launches:
+// Three launches:
 //  k_gather_sums (grid x K, HBM-streaming, many waves in flight): a Gaussian's per-instance partial-gradient rows -- one
-//    contiguous run by emission slot, a wave's 64 Gaussians one contiguous block -- are streamed through LDS with coalesced
-//    loads and added in emission order (the single-view kernel's gather, on its own so that its two dependent memory round
-//    trips overlap across ~6 waves per SIMD instead of stalling a register-heavy kernel); 48 bytes per Gaussian and view out.
-//  k_gaussian_bwd_batch: one workgroup = 64 Gaussians x NW waves (NW = min(K, 4)), wave w taking views w, w + NW, ...: the
-//    Gaussian's SH block is read ONCE for all K views (staged in LDS, shared by the waves), every wave runs the same
-//    per-Gaussian chain as the single-view kernel (gaussian_chain) on its view's sums, and the views' results are added
-//    into ONE LDS row per Gaussian in VIEW ORDER (the waves take turns) -- fixed order end to end, bit-reproducible.  The
-//    summed gradients are written once instead of K times; dL/dSH is summed in its factored form w_k(view dir) * g[ch].
+//    contiguous run by emission slot, a wave's 64 Gaussians one contiguous block -- are streamed with coalesced loads and
+//    added in emission order; 48 bytes per Gaussian and view out (gsum).
+//  k_chain_view + k_chain_sum: below.
 // one step of the keyed wave scan: lanes that receive a value through the DPP pattern CTRL (row mask ROWS) add it iff it comes from
 // the same owner; lanes the pattern does not reach see the key -1 and add nothing
 template <int CTRL, int ROWS>
@@ -652,201 +657,198 @@ __global__ __launch_bounds__(256) void k_gather_sums(int P, const int *__restric
   GSAJ_TRACE_END(gath)
 }
 
+// ---- the batched per-Gaussian backward: two launches --------------------------------------------------------------
+// (round 2 ran it as ONE kernel, 64 Gaussians x 4 waves, wave w taking views w, w + 4 with the SH backward inside: 213 VGPRs,
+// two waves per SIMD, a wave alive for 27 us of which 5 us issued instructions -- 70 us per cfg2 window.)
+//
+//  k_chain_view   grid (P / 256, K), lane = (view, Gaussian): the whole per-view chain on that view's sums (gaussian_chain_geom +
+//                 the view-direction term of the SH colour), no sum over views: K x P independent lanes fill the chip.  Writes the
+//                 view's per-Gaussian outputs (dL/dmean2D, ...), one row per (view, Gaussian) for the sums over views -- (dL/dopacity,
+//                 dL/dmean3D, dL/dcov3D, the colour gradient masked by the clamp flags, the SH basis weights of the view
+//                 direction) -- and a dL/dtau partial per wave.
+//  k_chain_sum    lane = (Gaussian, SH coefficient k), 16 lanes per Gaussian: adds the K views' rows IN VIEW ORDER (fixed order:
+//                 bit-reproducible) -- lane k < 10 component k of (dL/dopacity, dL/dmean3D, dL/dcov3D), every lane its
+//                 coefficient's dL/dSH[k][ch] = sum_v w_k(view) g_v[ch] -- all views' loads in flight together; lane 0 forms
+//                 dL/dscale, dL/drot ONCE from the summed dL/dcov3D (they are linear in it with view-independent coefficients).
+//                 Every summed output is written once (or added: GSAJ_BWD_ACCUMULATE).  Storage of at most one SH coefficient (SH-0
+//                 maps, precomputed colours): lane = Gaussian instead (16 lanes would share one 64-byte row per load).  K extra
+//                 workgroups, one per view, add that view's dL/dtau partials up in slot order (fp64): no tickets, no atomics.
+#define VROW_F4(MC) (4 + ((MC) > 1 ? ((MC) + 3) / 4 : 0))  // float4s per (view, Gaussian) row of GeomWS.vsum
 GSAJ_TRACE_DEFINE(gbb)
-#define GBB_MAX_WAVES 4  // measured at K = 8, cfg2: 2 waves 118 us, 4 waves 79 us, 8 waves 94 us (two workgroups per CU overlap their serial phases)
+
 template <int SHW>
-__global__ __launch_bounds__(GB_BLOCK * GBB_MAX_WAVES) void k_gaussian_bwd_batch(BwdParams p, int K, GeomWS g0, ImageWS im0,
-                                                                                 const float4 *__restrict__ inst_grad0,
-                                                                                 const uint8_t *__restrict__ reached0, ViewStrides vs,
-                                                                                 float *__restrict__ pv_mean2D, float *__restrict__ pv_conic,
-                                                                                 float *__restrict__ pv_color, float *__restrict__ pv_depth,
-                                                                                 float *__restrict__ pv_tau, int accumulate) {
-  constexpr int NACC = 17 + SHW;  // opacity, mean3D 3, cov3D 6, scale 3, rot 4, dL/dSH
+__global__ __launch_bounds__(256) void k_chain_view(BwdParams p, GeomWS g0, ImageWS im0, ViewStrides vs, float *__restrict__ pv_mean2D,
+                                                    float *__restrict__ pv_conic, float *__restrict__ pv_color,
+                                                    float *__restrict__ pv_depth, float *__restrict__ pv_tau) {
+  constexpr int MC = SHW / 3, ROW = VROW_F4(MC);
   GSAJ_TRACE_BEGIN(gbb)
-#ifdef GSAJ_BLOCK_TRACE
-  unsigned long long trb_[6] = {0, 0, 0, 0, 0, 0}, trb_t = wall_clock64();
-#define TRB(i) { const unsigned long long n_ = wall_clock64(); trb_[i] += n_ - trb_t; trb_t = n_; }
-#else
-#define TRB(i)
-#endif
-  constexpr int MC = SHW / 3;     // SH coefficients stored
-  constexpr int shs_stride = SHW + 1;
-  extern __shared__ float lds_dyn[];  // [64][SHW+1] SH coefficients | [NW][NACC][64] per-wave sums (component-major: conflict-free)
-  __shared__ uint32_t s_ticket;
-  const int tid = threadIdx.x & 63, wave = threadIdx.x >> 6, NW = blockDim.x >> 6;
-  const int idx = blockIdx.x * GB_BLOCK + tid;
-  float *sh_in = lds_dyn;
-  float *meet_all = lds_dyn + ((GB_BLOCK * shs_stride + 3) & ~3);
-  constexpr int CS = GB_BLOCK + 1;  // component stride (padded: the transposed dL/dSH store below stays conflict-free)
-  float *mine = meet_all + (size_t)wave * NACC * CS + tid;  // this wave's private sums: component k at mine[k * CS]
+  const int v = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  const GeomWS g = geom_view(g0, (size_t)v * vs.geom);
+  const uint32_t *counters = gsaj_shift(im0.counters, (size_t)v * vs.image);
+  const int idx = blockIdx.x * 256 + tid;
   const size_t ii = (size_t)(idx < p.P ? idx : 0);
-  // ---- inputs of this Gaussian: once for all views ----
+  // every input requested up front and unconditionally
+  const uint32_t aborted = counters[4];  // aborted async frame: contributes nothing
+  const int rad = p.radii[(size_t)v * p.P + ii];
+  const float4 s0 = g.gsum[3 * ii + 0], s1 = g.gsum[3 * ii + 1], s2 = g.gsum[3 * ii + 2];
   const float3 mean = make_float3(p.means3D[3 * ii], p.means3D[3 * ii + 1], p.means3D[3 * ii + 2]);
   float c6[6];
 #pragma unroll
   for (int k = 0; k < 6; k++) c6[k] = p.cov3Ds[6 * ii + k];  // (view 0's copy: Sigma = R S^2 R^T does not depend on the view)
-  float3 sc = make_float3(0.f, 0.f, 0.f);
-  float4 q = make_float4(1.f, 0.f, 0.f, 0.f);
-  if (p.scales) {
-    sc = make_float3(p.scales[3 * ii], p.scales[3 * ii + 1], p.scales[3 * ii + 2]);
-    q = reinterpret_cast<const float4 *>(p.rotations)[ii];
-  }
-  // A view's inputs for this Gaussian: radius, abort flag, clamp flags and the 10 gathered sums -- all requested together and
-  // unconditionally (a load that waits for another load's result costs a second ~2 us round trip at two waves per SIMD), and one
-  // view AHEAD: the first view's before the SH staging below, view v + NW's before the chain of view v.
-  struct ViewIn {
-    uint32_t ab;
-    int rad;
-    uint8_t cl[3];
-    float4 s0, s1, s2;
-  };
-  const int *radii0 = p.radii;
-  auto request = [&](int v, ViewIn &in) {
-    const int vc = min(v, K - 1);
-    const GeomWS g = geom_view(g0, (size_t)vc * vs.geom);
-    in.ab = gsaj_shift(im0.counters, (size_t)vc * vs.image)[4];
-    in.rad = radii0[(size_t)vc * p.P + ii];
-    in.cl[0] = in.cl[1] = in.cl[2] = 0;
-    if (SHW > 0) { in.cl[0] = g.clamped[3 * ii]; in.cl[1] = g.clamped[3 * ii + 1]; in.cl[2] = g.clamped[3 * ii + 2]; }
-    in.s0 = g.gsum[3 * ii + 0]; in.s1 = g.gsum[3 * ii + 1]; in.s2 = g.gsum[3 * ii + 2];
-  };
-  ViewIn nxt;
-  request(wave, nxt);
-  if (SHW > 0) {  // coalesced load of the workgroup's contiguous [64][M*3] SH block
-    const size_t base = (size_t)blockIdx.x * GB_BLOCK * SHW;
-    const int count = min(GB_BLOCK, p.P - blockIdx.x * GB_BLOCK) * SHW;
-    for (int e = threadIdx.x; e < count; e += (int)blockDim.x) {
-      const int gi = e / (SHW > 0 ? SHW : 1), k = e - gi * SHW;
-      sh_in[gi * shs_stride + k] = p.shs[base + e];
+  uint8_t cl[3] = {0, 0, 0};
+  if (SHW > 0) { cl[0] = g.clamped[3 * ii]; cl[1] = g.clamped[3 * ii + 1]; cl[2] = g.clamped[3 * ii + 2]; }
+  p.viewmatrix += 16 * v;
+  p.projmatrix += 16 * v;
+  const bool vis = idx < p.P && !aborted && rad > 0;
+  GaussianGrads o;
+  o.m2x = o.m2y = o.ca = o.cb = o.cc = o.op = o.dz = 0.f;
+  o.col = o.gm = make_float3(0.f, 0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < 6; k++) o.cov[k] = 0.f;
+  float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float w[MC > 0 ? MC : 1];  // SH basis weights of this view's direction
+#pragma unroll
+  for (int k = 0; k < MC; k++) w[k] = 0.f;
+  float3 gmask = make_float3(0.f, 0.f, 0.f);
+  if (vis) {
+    gaussian_chain_geom(p, mean, c6, s0, s1, s2, o, tau);
+    if (SHW > 0) {
+      const float *cam = p.campos + 3 * v;
+      constexpr int DEG_MAX = MC >= 16 ? 3 : (MC >= 9 ? 2 : (MC >= 4 ? 1 : 0));  // (the storage bounds the degree: dead bands compile away)
+      const float3 dmean = sh_backward<1>(min(p.D, DEG_MAX), p.M, mean, make_float3(cam[0], cam[1], cam[2]), p.shs + ii * SHW, w, cl, o.col);
+      o.gm.x += dmean.x; o.gm.y += dmean.y; o.gm.z += dmean.z;
+      tau[0] -= dmean.x; tau[1] -= dmean.y; tau[2] -= dmean.z;
+      gmask = make_float3(cl[0] ? 0.f : o.col.x, cl[1] ? 0.f : o.col.y, cl[2] ? 0.f : o.col.z);
     }
   }
-  __syncthreads();
-  TRB(0)  // inputs + SH staging + barrier
-  const float *vm0 = p.viewmatrix, *pj0 = p.projmatrix, *cam0 = p.campos;
-  for (int v0 = 0; v0 < K; v0 += NW) {
-    const int v = v0 + wave;
-    const ViewIn cur = nxt;
-    if (v0 + NW < K) request(v + NW, nxt);
-    GaussianGrads o;
-    o.m2x = o.m2y = o.ca = o.cb = o.cc = o.op = o.dz = 0.f;
-    o.col = o.gm = o.scale = make_float3(0.f, 0.f, 0.f);
-    o.rot = make_float4(0.f, 0.f, 0.f, 0.f);
+  // ---- this view's dL/dtau: wave partials (the single-view kernel's butterfly), one slot per 64 Gaussians, added up in slot order
+  // (fp64) by k_chain_sum's extra workgroups.  No ticket here: 31 256 workgroups (cfg5 window) drawing tickets from ONE word per
+  // view, all resident ones on the same view, run at the ~88 returning atomics per us a single address sustains
+  // (MI355X_MICROARCH.md, dequeue): 0.36 ms of a 1.2 ms kernel.
+  {
+    float t6[6];
 #pragma unroll
-    for (int k = 0; k < 6; k++) o.cov[k] = 0.f;
-    float shw[MC > 0 ? MC : 1];  // SH basis weights of this view's direction
+    for (int k = 0; k < 6; k++) {
+      float t = tau[k];
 #pragma unroll
-    for (int k = 0; k < MC; k++) shw[k] = 0.f;
-    float gmask[3] = {0.f, 0.f, 0.f};
-    if (v < K) {
-      const GeomWS g = geom_view(g0, (size_t)v * vs.geom);
-      p.viewmatrix = vm0 + 16 * v;
-      p.projmatrix = pj0 + 16 * v;
-      p.campos = cam0 ? cam0 + 3 * v : nullptr;
-      const bool aborted = cur.ab != 0u;  // aborted async frame: contributes nothing
-      const int radius = (idx < p.P && !aborted) ? cur.rad : 0;
-      const bool vis = radius > 0;
-      const uint8_t cl[3] = {cur.cl[0], cur.cl[1], cur.cl[2]};
-      // the Gaussian's 10 reverse-compositor sums of this view (k_gather_sums)
-      const float4 s0 = cur.s0, s1 = cur.s1, s2 = cur.s2;
-      float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#ifdef GSAJ_BLOCK_TRACE
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
-      TRB(1)  // this view's loads
-      if (vis) {
-        // (dL/dscale, dL/drot are linear in dL/dcov3D with view-independent coefficients: formed ONCE below from the sum over views)
-        gaussian_chain<true>(p, mean, c6, sc, q, cl, s0, s1, s2, sh_in + tid * shs_stride, shw, false, o, tau);
-        gmask[0] = cl[0] ? 0.f : o.col.x; gmask[1] = cl[1] ? 0.f : o.col.y; gmask[2] = cl[2] ? 0.f : o.col.z;
-      }
-      // per-view outputs
-      if (idx < p.P) {
-        const size_t row = (size_t)v * p.P + ii;
-        if (pv_mean2D) { pv_mean2D[3 * row] = o.m2x; pv_mean2D[3 * row + 1] = o.m2y; pv_mean2D[3 * row + 2] = 0.f; }
-        if (pv_conic) reinterpret_cast<float4 *>(pv_conic)[row] = make_float4(o.ca, o.cb, 0.f, o.cc);
-        if (pv_color) { pv_color[3 * row] = o.col.x; pv_color[3 * row + 1] = o.col.y; pv_color[3 * row + 2] = o.col.z; }
-        if (pv_depth) pv_depth[row] = o.dz;
-        if (pv_tau) {
-#pragma unroll
-          for (int k = 0; k < 6; k++) pv_tau[6 * row + k] = tau[k];
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 6; k++) {  // wave partial of this view's dL/dtau (same butterfly as the single-view kernel)
-        float t = tau[k];
-#pragma unroll
-        for (int o2 = 32; o2 > 0; o2 >>= 1) t += __shfl_xor(t, o2);
-        if (tid == 0) __hip_atomic_store(&g.tau_partials[(size_t)blockIdx.x * 8 + k], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      for (int o2 = 32; o2 > 0; o2 >>= 1) t += __shfl_xor(t, o2);
+      t6[k] = t;
     }
-    TRB(2)  // chain + per-view outputs + tau butterfly
-    // ---- this view is added to the wave's private sums (no other wave touches them) ----
-    if (v < K) {
-      const bool first_view = v0 == 0;  // (every wave has a view in the first round: NW <= K) stores instead of adds: no zero fill
-#define MADD(k, x) mine[(k) * CS] = first_view ? (x) : mine[(k) * CS] + (x)
-      MADD(0, o.op);
-      MADD(1, o.gm.x); MADD(2, o.gm.y); MADD(3, o.gm.z);
-#pragma unroll
-      for (int k = 0; k < 6; k++) MADD(4 + k, o.cov[k]);
-      MADD(10, 0.f); MADD(11, 0.f); MADD(12, 0.f); MADD(13, 0.f); MADD(14, 0.f); MADD(15, 0.f); MADD(16, 0.f);  // (unused slots)
-#pragma unroll
-      for (int k = 0; k < MC; k++) {
-        MADD(17 + 3 * k, shw[k] * gmask[0]);
-        MADD(17 + 3 * k + 1, shw[k] * gmask[1]);
-        MADD(17 + 3 * k + 2, shw[k] * gmask[2]);
-      }
-#undef MADD
+    if (lane == 0 && blockIdx.x * 256 + (tid & ~63) < p.P) {
+      float4 *tp = reinterpret_cast<float4 *>(g.tau_partials + ((size_t)blockIdx.x * 4 + (tid >> 6)) * 8);
+      tp[0] = make_float4(t6[0], t6[1], t6[2], t6[3]);
+      tp[1] = make_float4(t6[4], t6[5], 0.f, 0.f);
     }
   }
-  TRB(3)  // LDS sums
-  // ---- the waves' sums are added in wave order, every (component, Gaussian) by one thread: fixed order, bit-reproducible ----
-  __syncthreads();
-  for (int e = threadIdx.x; e < NACC * CS; e += (int)blockDim.x) {
-    float t = meet_all[e];
-    for (int w = 1; w < NW; w++) t += meet_all[(size_t)w * NACC * CS + e];
-    meet_all[e] = t;
-  }
-  __syncthreads();
-  TRB(4)  // barrier (waiting for the slowest wave) + cross-wave sums
-  // ---- dL/dtau: the last workgroup to arrive sums every view's partials in workgroup order (fp64) ----
-  if (threadIdx.x == 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    s_ticket = __hip_atomic_fetch_add(&im0.counters[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  TRB(4)  // (+ ticket)
-  if (s_ticket == gridDim.x - 1 && p.dL_dtau_sum) {
-    const int nblk = (int)gridDim.x;
-    for (int v = wave; v < K; v += NW) {
-      const float *tp = gsaj_shift(g0.tau_partials, (size_t)v * vs.geom);
-      double a6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-      // This workgroup works alone while the rest of the chip waits for the kernel to end (gsaj_load_partial); summed in workgroup order.
-      gsaj_sum_partials(tp, nblk, tid, a6);
+  if (idx < p.P) {
+    float4 *dst = g.vsum + (size_t)ROW * ii;
+    dst[0] = make_float4(o.op, o.gm.x, o.gm.y, o.gm.z);
+    dst[1] = make_float4(o.cov[0], o.cov[1], o.cov[2], o.cov[3]);
+    dst[2] = make_float4(o.cov[4], o.cov[5], gmask.x, gmask.y);
+    dst[3] = make_float4(gmask.z, 0.f, 0.f, 0.f);
+    if (MC > 1) {
 #pragma unroll
-      for (int k = 0; k < 6; k++) {
-        double t = a6[k];
-#pragma unroll
-        for (int o2 = 32; o2 > 0; o2 >>= 1) t += __shfl_xor(t, o2);
-        if (tid == 0) p.dL_dtau_sum[6 * v + k] = (float)t;
-      }
+      for (int k = 0; k < (MC + 3) / 4; k++)
+        dst[4 + k] = make_float4(w[4 * k], 4 * k + 1 < MC ? w[4 * k + 1] : 0.f, 4 * k + 2 < MC ? w[4 * k + 2] : 0.f, 4 * k + 3 < MC ? w[4 * k + 3] : 0.f);
     }
-    if (threadIdx.x == 0) im0.counters[3] = 0u;
+    const size_t row = (size_t)v * p.P + ii;
+    if (pv_mean2D) { pv_mean2D[3 * row] = o.m2x; pv_mean2D[3 * row + 1] = o.m2y; pv_mean2D[3 * row + 2] = 0.f; }
+    if (pv_conic) reinterpret_cast<float4 *>(pv_conic)[row] = make_float4(o.ca, o.cb, 0.f, o.cc);
+    if (pv_color) { pv_color[3 * row] = o.col.x; pv_color[3 * row + 1] = o.col.y; pv_color[3 * row + 2] = o.col.z; }
+    if (pv_depth) pv_depth[row] = o.dz;
+    if (pv_tau) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) pv_tau[6 * row + k] = tau[k];
+    }
   }
-  TRB(5)  // (+ the last workgroup's dL/dtau sums)
-  // ---- outputs, once per Gaussian ----
-  if (wave == 0 && idx < p.P) {
-#define MGET(k) meet_all[(k) * CS + tid]
-    // accumulate: this call's sums are ADDED to what the buffers hold (a window processed in several calls, or keyframes of several
-    // windows accumulated on one rank before the optimiser step: callers add in a fixed order, so the result stays reproducible)
+  GSAJ_TRACE_END(gbb)
+}
+
+GSAJ_TRACE_DEFINE(gbs)
+// workgroup `view` of the K extra ones: dL_dtau_sum[view] = sum of the view's per-wave partials in slot order, fp64
+__device__ __forceinline__ void chain_tau_sum(const BwdParams &p, const GeomWS &g0, ViewStrides vs, int view) {
+  __shared__ double red[256 * 6];
+  const int tid = threadIdx.x, nslot = (p.P + 63) / 64;
+  const float4 *tp = reinterpret_cast<const float4 *>(gsaj_shift(g0.tau_partials, (size_t)view * vs.geom));
+  double a[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int i = tid; i < nslot; i += 256) {
+    const float4 lo = tp[2 * i], hi = tp[2 * i + 1];
+    a[0] += (double)lo.x; a[1] += (double)lo.y; a[2] += (double)lo.z; a[3] += (double)lo.w; a[4] += (double)hi.x; a[5] += (double)hi.y;
+  }
+#pragma unroll
+  for (int k = 0; k < 6; k++) red[k * 256 + tid] = a[k];
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {  // fixed tree
+    if (tid < o) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) red[k * 256 + tid] += red[k * 256 + tid + o];
+    }
+    __syncthreads();
+  }
+  if (tid < 6 && p.dL_dtau_sum) p.dL_dtau_sum[6 * view + tid] = (float)red[tid * 256];
+}
+
+#define CS_VB 8  // views whose loads are in flight together
 #define OUT(dst, x) dst = accumulate ? dst + (x) : (x)
+// accumulate: this call's sums are ADDED to what the buffers hold (a window processed in several calls, or keyframes of several
+// windows accumulated on one rank before the optimiser step: callers add in a fixed order, so the result stays reproducible)
+template <int SHW>
+__global__ __launch_bounds__(256) void k_chain_sum(BwdParams p, int K, int nblk, GeomWS g0, ViewStrides vs, int accumulate) {
+  constexpr int MC = SHW / 3, ROW = VROW_F4(MC);
+  if ((int)blockIdx.x >= nblk) {
+    chain_tau_sum(p, g0, vs, (int)blockIdx.x - nblk);
+    return;
+  }
+  GSAJ_TRACE_BEGIN(gbs)
+  const int tid = threadIdx.x, k = tid & 15;
+  const int idx = blockIdx.x * 16 + (tid >> 4);
+  const bool live = idx < p.P;
+  const size_t ii = (size_t)(live ? idx : 0);
+  // lane k: component k of (dL/dopacity, dL/dmean3D, dL/dcov3D) for k < 10, and dL/dSH[k][0..2] for k < MC
+  const int comp = k < 10 ? k : 0;
+  float csum = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f;
+  for (int v0 = 0; v0 < K; v0 += CS_VB) {
+    float cv[CS_VB], wv[CS_VB];
+    float4 ga[CS_VB], gb[CS_VB];
+#pragma unroll
+    for (int j = 0; j < CS_VB; j++) {  // every load of these views requested before the first use (rows of views past K: view K-1's, unused)
+      const int v = min(v0 + j, K - 1);
+      const float *row = reinterpret_cast<const float *>(gsaj_shift(g0.vsum, (size_t)v * vs.geom) + (size_t)ROW * ii);
+      cv[j] = row[comp];
+      ga[j] = reinterpret_cast<const float4 *>(row)[2];  // (cov4, cov5, g0, g1)
+      gb[j] = reinterpret_cast<const float4 *>(row)[3];  // (g2, -, -, -)
+      wv[j] = row[16 + (k < MC ? k : 0)];
+    }
+#pragma unroll
+    for (int j = 0; j < CS_VB; j++) {
+      if (v0 + j < K) {
+        csum += cv[j];
+        d0 += wv[j] * ga[j].z;
+        d1 += wv[j] * ga[j].w;
+        d2 += wv[j] * gb[j].x;
+      }
+    }
+  }
+  // ---- outputs, once per Gaussian ----
+  if (live) {
     const size_t i = (size_t)idx;
-    OUT(p.dL_dopacity[i], MGET(0));
-    OUT(p.dL_dmean3D[3 * i], MGET(1)); OUT(p.dL_dmean3D[3 * i + 1], MGET(2)); OUT(p.dL_dmean3D[3 * i + 2], MGET(3));
+    if (k == 0) OUT(p.dL_dopacity[i], csum);
+    else if (k < 4) OUT(p.dL_dmean3D[3 * i + (k - 1)], csum);
+    else if (k < 10) OUT(p.dL_dcov3D[6 * i + (k - 4)], csum);
+    if (p.dL_dsh && k < MC) {
+      float *d = p.dL_dsh + i * SHW + 3 * k;
+      // (coefficients above the active degree have zero weights: their gradients come out zero)
+      OUT(d[0], d0); OUT(d[1], d1); OUT(d[2], d2);
+    }
+  }
+  if (p.scales) {  // dL/dscale, dL/drot from the summed dL/dcov3D (lanes 4..9 of the Gaussian's 16): lane 0
+    float gcov[6];
 #pragma unroll
-    for (int k = 0; k < 6; k++) OUT(p.dL_dcov3D[6 * i + k], MGET(4 + k));
-    if (p.scales) {
-      float gcov[6];
-#pragma unroll
-      for (int k = 0; k < 6; k++) gcov[k] = MGET(4 + k);  // (this call's part: dL/dscale, dL/drot are linear in it)
+    for (int c = 0; c < 6; c++) gcov[c] = __shfl(csum, (threadIdx.x & 48) + 4 + c, 64);  // (this call's part: both are linear in it)
+    if (live && k == 0) {
+      const size_t i = (size_t)idx;
+      const float3 sc = make_float3(p.scales[3 * i], p.scales[3 * i + 1], p.scales[3 * i + 2]);
+      const float4 q = reinterpret_cast<const float4 *>(p.rotations)[i];
       float3 dscale;
       float4 drot;
       cov3d_backward(gcov, sc, q, p.scale_modifier, dscale, drot);
@@ -855,42 +857,75 @@ __global__ __launch_bounds__(GB_BLOCK * GBB_MAX_WAVES) void k_gaussian_bwd_batch
       if (accumulate) { const float4 o4 = *dr; drot.x += o4.x; drot.y += o4.y; drot.z += o4.z; drot.w += o4.w; }
       *dr = drot;
     }
-#undef OUT
-#undef MGET
   }
-  if (SHW > 0 && p.dL_dsh) {  // coalesced store of the [64][M*3] block (coefficients above the active degree stay zero)
-    const size_t base = (size_t)blockIdx.x * GB_BLOCK * SHW;
-    const int count = min(GB_BLOCK, p.P - blockIdx.x * GB_BLOCK) * SHW;
-    for (int e = threadIdx.x; e < count; e += (int)blockDim.x) {
-      const int gi = e / (SHW > 0 ? SHW : 1), k = e - gi * SHW;
-      const float t = meet_all[(17 + k) * CS + gi];
-      p.dL_dsh[base + e] = accumulate ? p.dL_dsh[base + e] + t : t;
-    }
-  }
-  GSAJ_TRACE_END(gbb)
-#ifdef GSAJ_BLOCK_TRACE
-  {
-    const unsigned tw_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if ((threadIdx.x & 63) == 0 && tw_ < GSAJ_TRACE_MAX) {
-      g_trace_gbb[4 * tw_ + 2] = (trb_[0] << 42) | (trb_[1] << 21) | trb_[2];
-      g_trace_gbb[4 * tw_ + 3] = (trb_[3] << 42) | (trb_[4] << 21) | trb_[5];
-    }
-  }
-#endif
-#undef TRB
+  GSAJ_TRACE_END(gbs)
 }
 
+// at most one SH coefficient stored (SHW = 0: precomputed colours; 3: SH-0 maps): lane = Gaussian, the K rows of 64 bytes read whole
 template <int SHW>
-static void launch_gbb(const BwdParams &p, int K, const GeomWS &g, const BinWS &b, const ImageWS &im, ViewStrides vs, int accumulate,
-                       hipStream_t s) {
-  const int nblk = (p.P + GB_BLOCK - 1) / GB_BLOCK;
-  const int nw = K < GBB_MAX_WAVES ? K : GBB_MAX_WAVES;
-  const size_t sh_floats = ((size_t)GB_BLOCK * (SHW + 1) + 3) & ~(size_t)3;
-  const size_t meet = (size_t)nw * (17 + SHW) * (GB_BLOCK + 1);
-  const size_t lds = sizeof(float) * (sh_floats + meet);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gaussian_bwd_batch<SHW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k_gaussian_bwd_batch<SHW>, dim3(nblk), dim3(GB_BLOCK * nw), lds, s, p, K, g, im, b.inst_grad, b.reached, vs,
-                     p.dL_dmean2D, p.dL_dconic, p.dL_dcolor, p.dL_ddepth, p.dL_dtau, accumulate);
+__global__ __launch_bounds__(256) void k_chain_sum1(BwdParams p, int K, int nblk, GeomWS g0, ViewStrides vs, int accumulate) {
+  static_assert(SHW == 0 || SHW == 3, "one coefficient at most");
+  constexpr int ROW = VROW_F4(SHW / 3);
+  if ((int)blockIdx.x >= nblk) {
+    chain_tau_sum(p, g0, vs, (int)blockIdx.x - nblk);
+    return;
+  }
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= p.P) return;
+  const size_t i = (size_t)idx;
+  float acc[13];
+#pragma unroll
+  for (int c = 0; c < 13; c++) acc[c] = 0.f;
+  for (int v0 = 0; v0 < K; v0 += 4) {
+    float4 r[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const float4 *row = gsaj_shift(g0.vsum, (size_t)min(v0 + j, K - 1) * vs.geom) + (size_t)ROW * i;
+      r[j][0] = row[0]; r[j][1] = row[1]; r[j][2] = row[2]; r[j][3] = row[3];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (v0 + j < K) {
+        acc[0] += r[j][0].x; acc[1] += r[j][0].y; acc[2] += r[j][0].z; acc[3] += r[j][0].w;
+        acc[4] += r[j][1].x; acc[5] += r[j][1].y; acc[6] += r[j][1].z; acc[7] += r[j][1].w;
+        acc[8] += r[j][2].x; acc[9] += r[j][2].y; acc[10] += r[j][2].z; acc[11] += r[j][2].w; acc[12] += r[j][3].x;
+      }
+    }
+  }
+  OUT(p.dL_dopacity[i], acc[0]);
+  OUT(p.dL_dmean3D[3 * i], acc[1]); OUT(p.dL_dmean3D[3 * i + 1], acc[2]); OUT(p.dL_dmean3D[3 * i + 2], acc[3]);
+#pragma unroll
+  for (int c = 0; c < 6; c++) OUT(p.dL_dcov3D[6 * i + c], acc[4 + c]);
+  if (SHW > 0 && p.dL_dsh) {  // dL/dSH[0][ch] = C0 x the summed masked colour gradient
+    const float C0 = 0.28209479177387814f;
+    OUT(p.dL_dsh[3 * i], C0 * acc[10]); OUT(p.dL_dsh[3 * i + 1], C0 * acc[11]); OUT(p.dL_dsh[3 * i + 2], C0 * acc[12]);
+  }
+  if (p.scales) {
+    const float gcov[6] = {acc[4], acc[5], acc[6], acc[7], acc[8], acc[9]};
+    const float3 sc = make_float3(p.scales[3 * i], p.scales[3 * i + 1], p.scales[3 * i + 2]);
+    const float4 q = reinterpret_cast<const float4 *>(p.rotations)[i];
+    float3 dscale;
+    float4 drot;
+    cov3d_backward(gcov, sc, q, p.scale_modifier, dscale, drot);
+    OUT(p.dL_dscale[3 * i], dscale.x); OUT(p.dL_dscale[3 * i + 1], dscale.y); OUT(p.dL_dscale[3 * i + 2], dscale.z);
+    float4 *dr = reinterpret_cast<float4 *>(p.dL_drot) + i;
+    if (accumulate) { const float4 o4 = *dr; drot.x += o4.x; drot.y += o4.y; drot.z += o4.z; drot.w += o4.w; }
+    *dr = drot;
+  }
+}
+#undef OUT
+
+template <int SHW>
+static void launch_chain(const BwdParams &p, int K, const GeomWS &g, const ImageWS &im, ViewStrides vs, int accumulate, hipStream_t s) {
+  hipLaunchKernelGGL(k_chain_view<SHW>, dim3((p.P + 255) / 256, K), dim3(256), 0, s, p, g, im, vs, p.dL_dmean2D, p.dL_dconic, p.dL_dcolor,
+                     p.dL_ddepth, p.dL_dtau);
+  if constexpr (SHW <= 3) {
+    const int nblk = (p.P + 255) / 256;
+    hipLaunchKernelGGL(k_chain_sum1<SHW>, dim3(nblk + K), dim3(256), 0, s, p, K, nblk, g, vs, accumulate);
+  } else {
+    const int nblk = (p.P + 15) / 16;
+    hipLaunchKernelGGL(k_chain_sum<SHW>, dim3(nblk + K), dim3(256), 0, s, p, K, nblk, g, vs, accumulate);
+  }
 }
 
 int launch_gather_sums(int P, int K, const int *radii, const GeomWS &g, const BinWS &b, const ImageWS &im, ViewStrides vs, hipStream_t s) {
@@ -902,13 +937,14 @@ int launch_gather_sums(int P, int K, const int *radii, const GeomWS &g, const Bi
 
 int launch_gaussian_backward_batch(const BwdParams &p, int K, const GeomWS &g, const BinWS &b, const ImageWS &im, ViewStrides vs,
                                    int accumulate, hipStream_t s) {
+  (void)b;
   GsajProfScope ps(ST_GAUSSIAN_BWD, s);
   switch (p.shs ? p.M : 0) {
-    case 0: launch_gbb<0>(p, K, g, b, im, vs, accumulate, s); break;
-    case 1: launch_gbb<3>(p, K, g, b, im, vs, accumulate, s); break;
-    case 4: launch_gbb<12>(p, K, g, b, im, vs, accumulate, s); break;
-    case 9: launch_gbb<27>(p, K, g, b, im, vs, accumulate, s); break;
-    case 16: launch_gbb<48>(p, K, g, b, im, vs, accumulate, s); break;
+    case 0: launch_chain<0>(p, K, g, im, vs, accumulate, s); break;
+    case 1: launch_chain<3>(p, K, g, im, vs, accumulate, s); break;
+    case 4: launch_chain<12>(p, K, g, im, vs, accumulate, s); break;
+    case 9: launch_chain<27>(p, K, g, im, vs, accumulate, s); break;
+    case 16: launch_chain<48>(p, K, g, im, vs, accumulate, s); break;
     default:
       gsaj_set_error("batched backward: SH storage of %d coefficients is not supported (1, 4, 9 or 16)", p.M);
       return GSAJ_ERR_INVALID_ARGUMENT;

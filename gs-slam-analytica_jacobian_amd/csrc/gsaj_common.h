@@ -48,7 +48,10 @@ struct GeomWS {  // per-Gaussian state (reference: GeometryState, rasterizer_imp
   uint4 *scat;              // [P] what the instance scatter reads: (depth bits, x0 | x1 << 16, y0 | y1 << 16, first emission
                             //   slot inside the block); x1 == x0: the Gaussian has no tile
   float4 *gsum;             // [P*3] batched backward: the Gaussian's 10 reverse-compositor sums (its instance rows added in
-                            //   emission order by k_gather_sums), read by k_gaussian_bwd_batch
+                            //   emission order by k_gather_sums), read by k_chain_view
+  float4 *vsum;             // [P*8] batched backward: this view's row of every Gaussian (k_chain_view), summed over the views by
+                            //   k_chain_sum: (dL/dopacity, dL/dmean3D | dL/dcov3D 0..3 | 4, 5, masked colour gradient r, g | b, -, -, - |
+                            //   up to 16 SH basis weights); 4 + ceil(M / 4) float4s per row are used
 };
 
 static inline __host__ __device__ size_t geom_carve(char *base, size_t P, GeomWS *g) {
@@ -75,6 +78,7 @@ static inline __host__ __device__ size_t geom_carve(char *base, size_t P, GeomWS
   CARVE(splat16, float4, P * 2);
   CARVE(scat, uint4, P);
   CARVE(gsum, float4, P * 3);
+  CARVE(vsum, float4, P * 8);
   return off;
 }
 
@@ -147,7 +151,7 @@ __device__ __forceinline__ GeomWS geom_view(GeomWS g, size_t off) {
   g.tiles_touched = gsaj_shift(g.tiles_touched, off); g.point_offsets = gsaj_shift(g.point_offsets, off);
   g.internal_radii = gsaj_shift(g.internal_radii, off); g.block_sums = gsaj_shift(g.block_sums, off);
   g.tau_partials = gsaj_shift(g.tau_partials, off); g.splat = gsaj_shift(g.splat, off); g.gsum = gsaj_shift(g.gsum, off);
-  g.splat16 = gsaj_shift(g.splat16, off); g.scat = gsaj_shift(g.scat, off);
+  g.splat16 = gsaj_shift(g.splat16, off); g.scat = gsaj_shift(g.scat, off); g.vsum = gsaj_shift(g.vsum, off);
   return g;
 }
 __device__ __forceinline__ ImageWS image_view(ImageWS m, size_t off) {

@@ -35,8 +35,8 @@ def main():
         bc.backward(bg, means, views, projs, praw, cps, cam["tanfovx"], cam["tanfovy"], dLc, dLd, **kw)
     torch.cuda.synchronize()
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
-    counts = {"pre": ((P + 255) // 256) * 4 * K, "scat": ((P + 255) // 256) * 4 * K, "sort": tiles * 4 * K, "fwd": tiles * 4 * K, "bwd": tiles * 4 * K,
-              "gath": ((P + 255) // 256) * 4 * K, "gbb": ((P + 63) // 64) * 4}
+    counts = {"pre": ((P + 255) // 256) * 4 * K, "scat": ((P + 2047) // 2048) * 8 * 4 * K, "sort": tiles * 4 * K, "fwd": tiles * 4 * K, "bwd": tiles * 4 * K,
+              "gath": ((P + 255) // 256) * 4 * K, "gbb": ((P + 255) // 256) * 4 * K, "gbs": (P + 63) // 64}
     for name, n in counts.items():
         fn = getattr(lib, "gsaj_trace_read_" + name, None)
         if fn is None:
@@ -56,7 +56,7 @@ def main():
                  *np.percentile((e - t0) * 0.01, [50, 95, 99]), busy))
         first = int(((s - t0) * 0.01 < 3.0).sum())
         print("      resident at once (waves started within the first 3 us): %d" % first)
-        if name in ("pre", "scat"):  # phase stamps (indexed by workgroup only: one view's, whichever wrote last)
+        if name == "pre":  # phase stamps (indexed by workgroup only: one view's, whichever wrote last)
             nb = ((P + 255) // 256) * 4
             raw = np.zeros((nb, 4), np.uint64)
             fn(raw.ctypes.data, nb)
