@@ -499,11 +499,15 @@ int gsaj_debug_export(int P, int R, int W, int H, const void *geom_ws, const voi
   if (geom_ws) {
     GeomWS g;
     geom_carve(align_base(const_cast<void *>(geom_ws)), Pz, &g);
-    CP(means2D, g.means2D, sizeof(float2) * Pz);
+    // means2D, conic_opacity, rgb live in the 48-byte splat rows only: strided copies
+#define CP2D(dst, src, width) \
+  if (dst) GSAJ_HIP_CHECK(hipMemcpy2DAsync(dst, width, src, sizeof(float4) * REC_F4, width, Pz, hipMemcpyDeviceToDevice, s))
+    CP2D(means2D, g.splat, sizeof(float2));
+    CP2D(conic_opacity, g.splat + 1, sizeof(float4));
+    CP2D(rgb, g.splat + 2, sizeof(float) * 3);
+#undef CP2D
     CP(depths, g.depths, sizeof(float) * Pz);
     CP(cov3D, g.cov3D, sizeof(float) * 6 * Pz);
-    CP(conic_opacity, g.conic_opacity, sizeof(float4) * Pz);
-    CP(rgb, g.rgb, sizeof(float) * 3 * Pz);
     CP(clamped, g.clamped, 3 * Pz);
     CP(tiles_touched, g.tiles_touched, sizeof(uint32_t) * Pz);
   }

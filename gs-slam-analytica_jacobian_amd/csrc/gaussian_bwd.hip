@@ -605,21 +605,31 @@ __global__ __launch_bounds__(256) void k_gather_sums(int P, const int *__restric
 #pragma unroll
   for (int c = 0; c < 10; c++) sum[c] = 0.f;
   if (F != 0xffffffffu && F < E) {
+    // rows the reverse compositor never wrote (`reached` = 0: no pixel of the tile got that far -- most of an opaque scene's
+    // instances) are not fetched: the one-byte flags run TWO groups ahead of the rows they admit, the rows one group ahead of
+    // their use; only the wave's first group is fetched without waiting for its flags
     float4 a0, a1, a2;
-    uint8_t fl;
-    auto request = [&](uint32_t base) {
-      const uint32_t r = min(base + (uint32_t)lane, E - 1);
-      fl = reached[r];
-      const float4 *src = inst_grad + (size_t)r * REC_F4;
+    uint8_t fl = 0, fl_a = 0, fl_b = 0;  // flags of the group in (a0, a1, a2), of the next group, of the one after
+    auto flags_of = [&](uint32_t base) -> uint8_t { return base + (uint32_t)lane < E ? reached[base + lane] : (uint8_t)0; };
+    auto rows_of = [&](uint32_t base) {
+      const float4 *src = inst_grad + (size_t)(base + lane) * REC_F4;
       a0 = src[0]; a1 = src[1]; a2 = src[2];
     };
-    request(F);
+    fl = flags_of(F);
+    if (F + (uint32_t)lane < E) rows_of(F);
+    fl_a = flags_of(F + 64);
+    fl_b = flags_of(F + 128);
     for (uint32_t base = F; base < E; base += 64) {
       const uint32_t r = base + (uint32_t)lane;
-      const bool ok = r < E && fl;
+      const bool ok = fl != 0;
       float v[10] = {ok ? a0.x : 0.f, ok ? a0.y : 0.f, ok ? a0.z : 0.f, ok ? a0.w : 0.f, ok ? a1.x : 0.f,
                      ok ? a1.y : 0.f, ok ? a1.z : 0.f, ok ? a1.w : 0.f, ok ? a2.x : 0.f, ok ? a2.y : 0.f};
-      if (base + 64 < E) request(base + 64);
+      if (base + 64 < E) {
+        fl = fl_a;
+        if (fl) rows_of(base + 64);
+        fl_a = fl_b;
+        fl_b = flags_of(base + 192);
+      }
       // owner of row r = number of owners whose end slot is <= r (end slots are non-decreasing): binary search by shuffles
       int own = 0;
 #pragma unroll

@@ -31,11 +31,8 @@
 static inline __host__ __device__ size_t gsaj_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct GeomWS {  // per-Gaussian state (reference: GeometryState, rasterizer_impl.h:29-44)
-  float *depths;          // [P]
-  float2 *means2D;        // [P]
-  float *cov3D;           // [P*6]
-  float4 *conic_opacity;  // [P]
-  float *rgb;             // [P*3]
+  float *depths;          // [P] view-space depth: the tile sort gathers it by id for its (depth, id) keys
+  float *cov3D;           // [P*6] (a batched launch writes view 0's only: Sigma = R S^2 R^T does not depend on the view)
   uint8_t *clamped;       // [P*3]
   uint32_t *tiles_touched;  // [P]
   uint32_t *point_offsets;  // [P] inclusive scan of tiles_touched INSIDE the Gaussian's block of PRE_BLOCK; + block_sums[block] = global
@@ -45,8 +42,7 @@ struct GeomWS {  // per-Gaussian state (reference: GeometryState, rasterizer_imp
   float4 *splat;            // [P*3] the per-Gaussian row both compositors gather through the sorted id list (above)
   float4 *splat16;          // [P*2] fp16-storage form of the row (GSAJ_FWD_RECORDS_FP16; written by k_pack_splat16):
                             //   (mean2D.x, mean2D.y, depth, first emission slot) (half2 a b, half2 c o, half2 r g, half2 b 0)
-  uint4 *scat;              // [P] what the instance scatter reads: (depth bits, x0 | x1 << 16, y0 | y1 << 16, first emission
-                            //   slot inside the block); x1 == x0: the Gaussian has no tile
+  uint2 *scat;              // [P] what the instance scatter reads: the tile rectangle (x0 | x1 << 16, y0 | y1 << 16); x1 == x0: no tile
   float4 *gsum;             // [P*3] batched backward: the Gaussian's 10 reverse-compositor sums (its instance rows added in
                             //   emission order by k_gather_sums), read by k_chain_view
   float4 *vsum;             // [P*8] batched backward: this view's row of every Gaussian (k_chain_view), summed over the views by
@@ -64,10 +60,7 @@ static inline __host__ __device__ size_t geom_carve(char *base, size_t P, GeomWS
     off += gsaj_align(sizeof(type) * (size_t)(count));           \
   } while (0)
   CARVE(depths, float, P);
-  CARVE(means2D, float2, P);
   CARVE(cov3D, float, P * 6);
-  CARVE(conic_opacity, float4, P);
-  CARVE(rgb, float, P * 3);
   CARVE(clamped, uint8_t, P * 3);
   CARVE(tiles_touched, uint32_t, P);
   CARVE(point_offsets, uint32_t, P);
@@ -76,7 +69,7 @@ static inline __host__ __device__ size_t geom_carve(char *base, size_t P, GeomWS
   CARVE(tau_partials, float, ((P + GB_BLOCK - 1) / GB_BLOCK + 1) * 8);
   CARVE(splat, float4, P * 3);
   CARVE(splat16, float4, P * 2);
-  CARVE(scat, uint4, P);
+  CARVE(scat, uint2, P);
   CARVE(gsum, float4, P * 3);
   CARVE(vsum, float4, P * 8);
   return off;
@@ -86,7 +79,7 @@ static inline __host__ __device__ size_t geom_carve(char *base, size_t P, GeomWS
 #define LDS_TILES_MAX 8192  // images with more tiles than this bin with direct global atomics
 #define SORT_CAP 16384    // largest tile list sorted in ONE LDS pass (128 KB of the CU's 160 KB LDS); longer lists: LDS-sized chunks + merge passes
 #define N_COUNTERS 64     // frame counters: [0] num_rendered [1] error flags [2] longest tile list [3] tau ticket
-                          //   [5] preprocess ticket (last workgroup runs the frame scan)
+                          //   [5] (unused)
                           //   [4] abort (async forward: arena too small / tile list too long -> later kernels return)
 #define ERR_PREFILTERED 1u
 #define ERR_INTERNAL 2u
@@ -126,9 +119,9 @@ static inline __host__ __device__ size_t image_carve(char *base, int W, int H, I
 }
 
 struct BinWS {  // reference: BinningState, rasterizer_impl.h:55-66
-  uint64_t *keys_unsorted;  // [R] (depth bits << 32 | id), grouped by tile (k_scatter_instances)
-  uint64_t *keys;           // [R] second key buffer: merge passes of tile lists longer than the LDS sort capacity
-  uint32_t *point_list;     // [R] sorted Gaussian ids
+  uint64_t *keys_unsorted;  // [R] the two key buffers of tile lists longer than the LDS sort capacity (chunk sort -> merge passes);
+  uint64_t *keys;           // [R]   keys are (depth bits << 32 | id)
+  uint32_t *point_list;     // [R] Gaussian ids grouped by tile: as scattered (k_scatter_instances), then sorted in place (k_tile_sort)
   float4 *inst_grad;        // [R*3] per-instance partial gradients (backward), indexed by emission slot
   uint8_t *reached;         // [R] by emission slot: 1 = the reverse compositor wrote that row, 0 = no pixel of the tile got that far
                             //   (zeroed by the tile sort, set by the reverse compositor)
@@ -146,8 +139,7 @@ __device__ __forceinline__ T *gsaj_shift(T *p, size_t bytes) {
   return reinterpret_cast<T *>(reinterpret_cast<uintptr_t>(p) + bytes);
 }
 __device__ __forceinline__ GeomWS geom_view(GeomWS g, size_t off) {
-  g.depths = gsaj_shift(g.depths, off); g.means2D = gsaj_shift(g.means2D, off); g.cov3D = gsaj_shift(g.cov3D, off);
-  g.conic_opacity = gsaj_shift(g.conic_opacity, off); g.rgb = gsaj_shift(g.rgb, off); g.clamped = gsaj_shift(g.clamped, off);
+  g.depths = gsaj_shift(g.depths, off); g.cov3D = gsaj_shift(g.cov3D, off); g.clamped = gsaj_shift(g.clamped, off);
   g.tiles_touched = gsaj_shift(g.tiles_touched, off); g.point_offsets = gsaj_shift(g.point_offsets, off);
   g.internal_radii = gsaj_shift(g.internal_radii, off); g.block_sums = gsaj_shift(g.block_sums, off);
   g.tau_partials = gsaj_shift(g.tau_partials, off); g.splat = gsaj_shift(g.splat, off); g.gsum = gsaj_shift(g.gsum, off);

@@ -103,13 +103,11 @@ __device__ __forceinline__ float3 sh_to_rgb(int deg, float3 pos, float3 campos, 
   return make_float3(out[0], out[1], out[2]);
 }
 
-__device__ void frame_scan(int nblk, int tiles, int capacity, uint32_t *block_sums, ImageWS im, uint32_t *lds_tiles);
-
 GSAJ_TRACE_DEFINE(pre)
 
 __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__restrict__ radii, int *__restrict__ n_touched,
                                                          GeomWS g, ImageWS im, ViewStrides vs) {
-  __shared__ uint32_t scan[PRE_BLOCK];
+  __shared__ uint32_t scan[PRE_BLOCK / 64];
   extern __shared__ uint32_t hist[];  // [tiles] workgroup-local tile histogram (when tiles <= LDS_TILES_MAX)
   {  // batched launch: blockIdx.y = view (its own camera, workspaces and per-view outputs; the Gaussians are shared)
     const size_t view = blockIdx.y;
@@ -221,14 +219,11 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__re
     radii[idx] = my_radius_i;
     n_touched[idx] = 0;
     g.depths[idx] = depth;
-    g.means2D[idx] = xy;
-    g.conic_opacity[idx] = con_o;
-    if (!p.cov3D_precomp) {
+    if (!p.cov3D_precomp && blockIdx.y == 0) {  // (a batched launch: the views share the Gaussians, view 0's copy serves all)
 #pragma unroll
       for (int k = 0; k < 6; k++) g.cov3D[6 * (size_t)idx + k] = c6s[k];
     }
     if (!p.colors_precomp) {
-      g.rgb[3 * (size_t)idx] = rgb.x; g.rgb[3 * (size_t)idx + 1] = rgb.y; g.rgb[3 * (size_t)idx + 2] = rgb.z;
       g.clamped[3 * (size_t)idx] = cl[0]; g.clamped[3 * (size_t)idx + 1] = cl[1]; g.clamped[3 * (size_t)idx + 2] = cl[2];
     }
     g.tiles_touched[idx] = touched;
@@ -239,58 +234,51 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__re
     g.splat[3 * (size_t)idx + 2] = make_float4(rgb.x, rgb.y, rgb.z, depth);
   }
   TRP(0)
-  // block-local inclusive scan of tiles_touched (Hillis-Steele over 256 lanes)
-  scan[tid] = touched;
-  __syncthreads();
+  // block-local inclusive scan of tiles_touched: wave scans (shuffles) + one LDS hop for the four wave totals
+  uint32_t incl = touched;
+  {
+    const int lane = tid & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
+      if (lane >= o) incl += v;
+    }
+    if (lane == 63) scan[tid >> 6] = incl;
+  }
+  __syncthreads();  // (also: every thread's LDS histogram atomics are done)
   if (use_lds)
     for (int t = tid; t < tiles; t += PRE_BLOCK) {
       const uint32_t c = hist[t];
       if (c) atomicAdd(&im.tile_count[t], c);
     }
+  uint32_t block_total = 0;
 #pragma unroll
-  for (int o = 1; o < PRE_BLOCK; o <<= 1) {
-    uint32_t v = (tid >= o) ? scan[tid - o] : 0u;
-    __syncthreads();
-    scan[tid] += v;
-    __syncthreads();
+  for (int w = 0; w < PRE_BLOCK / 64; w++) {
+    const uint32_t v = scan[w];
+    if (w < (tid >> 6)) incl += v;
+    block_total += v;
   }
   if (idx < p.P) {
     // emission slots are counted inside the block; + block_sums[block] (its exclusive offset once the frame scan below has run)
-    const uint32_t first = scan[tid] - touched;
-    g.point_offsets[idx] = scan[tid];
+    const uint32_t first = incl - touched;
+    g.point_offsets[idx] = incl;
     reinterpret_cast<float *>(g.splat)[12 * (size_t)idx + 3] = __uint_as_float(first);
-    g.scat[idx] = make_uint4(__float_as_uint(depth), rect_x, rect_y, first);
+    g.scat[idx] = make_uint2(rect_x, rect_y);
   }
-  if (tid == PRE_BLOCK - 1)  // write-through (sc1): read by the last workgroup below
-    __hip_atomic_store(&g.block_sums[blockIdx.x], scan[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // ---- the last workgroup to arrive scans the per-workgroup totals and the tile histogram ----
-  // hand-off (counter form): every wave drains its histogram atomics / sc1 store, the workgroup
-  // meets at a barrier, one lane draws a relaxed agent-scope ticket; the last arriver reads the
-  // other workgroups' data with sc1 loads only.
+  if (tid == 0) g.block_sums[blockIdx.x] = block_total;  // block totals -> exclusive offsets: k_frame_scan
   TRP(1)
-  __shared__ uint32_t s_last;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0)
-    s_last = __hip_atomic_fetch_add(&im.counters[5], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
-  __syncthreads();
-  TRP(2)
-  if (s_last) frame_scan((int)gridDim.x, tiles, p.capacity, g.block_sums, im, use_lds ? hist : nullptr);
-  TRP(3)
   GSAJ_TRACE_END(pre)
 #ifdef GSAJ_BLOCK_TRACE
   if ((threadIdx.x & 63) == 0) {
     unsigned long long *t = g_trace_pre + 4 * (blockIdx.x * (PRE_BLOCK / 64) + (threadIdx.x >> 6));
     t[2] = (trp_[0] << 32) | trp_[1];
-    t[3] = (trp_[2] << 32) | trp_[3];
+    t[3] = 0;
   }
 #endif
 }
 
 // Exclusive scan of n items by ONE workgroup of PRE_BLOCK lanes: each lane sums a contiguous run, the
-// run totals are scanned with wave shuffles + one LDS hop, then each lane rewrites its run.  Inputs
-// were produced by OTHER workgroups of the same launch (sc1 stores / L2 atomics), so they are read
-// with sc1 (L1-bypassing) loads.  Returns the total.
+// run totals are scanned with wave shuffles + one LDS hop, then each lane rewrites its run.  Returns the total.
 __device__ uint32_t tail_exclusive_scan(const uint32_t *in, uint32_t *out, int n, uint32_t *run_max) {
   __shared__ uint32_t wsum[PRE_BLOCK / 64];
   __shared__ uint32_t wmax[PRE_BLOCK / 64];
@@ -299,7 +287,7 @@ __device__ uint32_t tail_exclusive_scan(const uint32_t *in, uint32_t *out, int n
   const int b0 = min(n, tid * per), b1 = min(n, b0 + per);
   uint32_t s = 0, mx = 0;
   for (int i = b0; i < b1; i++) {
-    const uint32_t v = __hip_atomic_load(&in[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t v = in[i];
     s += v;
     mx = max(mx, v);
   }
@@ -325,7 +313,7 @@ __device__ uint32_t tail_exclusive_scan(const uint32_t *in, uint32_t *out, int n
   if (run_max) *run_max = m;
   uint32_t run = woff + incl - s;
   for (int i = b0; i < b1; i++) {
-    const uint32_t v = __hip_atomic_load(&in[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t v = in[i];
     out[i] = run;
     run += v;
   }
@@ -343,7 +331,7 @@ __device__ uint32_t tile_scan_and_schedule(int tiles, ImageWS im, uint32_t *len,
   __shared__ uint32_t wsum[PRE_BLOCK / 64], wmax[PRE_BLOCK / 64], cls[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int c = tid; 4 * c < tiles; c += PRE_BLOCK) {  // (reads up to 3 words past `tiles`: still inside the zeroed counter block)
-    const uint4 v = gsaj_coherent_load_x4(im.tile_count + 4 * c);
+    const uint4 v = *reinterpret_cast<const uint4 *>(im.tile_count + 4 * c);
     len[4 * c] = v.x;
     if (4 * c + 1 < tiles) len[4 * c + 1] = v.y;
     if (4 * c + 2 < tiles) len[4 * c + 2] = v.z;
@@ -404,16 +392,22 @@ __device__ uint32_t tile_scan_and_schedule(int tiles, ImageWS im, uint32_t *len,
   return total;
 }
 
-// Run by the LAST workgroup of k_preprocess to arrive (replaces cub::DeviceScan of
-// rasterizer_impl.cu:327 and a separate launch): (1) exclusive offsets of the per-workgroup Gaussian
-// totals and the grand total R; (2) exclusive offsets of the per-tile histogram; (3) the longest
-// tile list; (4) for the async forward, the device-side capacity check.
-__device__ void frame_scan(int nblk, int tiles, int capacity, uint32_t *block_sums, ImageWS im, uint32_t *lds_tiles) {
+// One workgroup per view, launched behind k_preprocess (replaces cub::DeviceScan of rasterizer_impl.cu:327): (1) exclusive offsets
+// of the per-workgroup Gaussian totals and the grand total R; (2) exclusive offsets of the per-tile histogram and the tile
+// schedule; (3) the longest tile list; (4) for the async forward, the device-side capacity check.
+// (Rounds 1-2 had the LAST workgroup of k_preprocess to arrive do this, found with a ticket counter: a window of 10^6-Gaussian
+// frames draws 31 256 tickets, all resident workgroups from ONE word at ~88 returning atomics per us -- 0.36 ms.  A launch
+// boundary costs 2 us.)
+__global__ __launch_bounds__(PRE_BLOCK) void k_frame_scan(int nblk, int tiles, int capacity, GeomWS g, ImageWS im, ViewStrides vs) {
+  extern __shared__ uint32_t lds_len[];  // [tiles] when tiles <= LDS_TILES_MAX
+  g = geom_view(g, (size_t)blockIdx.y * vs.geom);
+  im = image_view(im, (size_t)blockIdx.y * vs.image);
+  uint32_t *block_sums = g.block_sums;
   const uint32_t R = tail_exclusive_scan(block_sums, block_sums, nblk, nullptr);
   uint32_t m = 0, R2;
-  if (lds_tiles) {
-    R2 = tile_scan_and_schedule(tiles, im, lds_tiles, &m);
-  } else {  // more tiles than the LDS histogram holds (> 8192: beyond 2048 x 1024 pixels): scan from memory, tiles in index order
+  if (tiles <= LDS_TILES_MAX) {
+    R2 = tile_scan_and_schedule(tiles, im, lds_len, &m);
+  } else {  // more tiles than the LDS copy holds (> 8192: beyond 2048 x 1024 pixels): scan from memory, tiles in index order
     R2 = tail_exclusive_scan(im.tile_count, im.tile_offset, tiles, &m);
     for (int t = threadIdx.x; t < tiles; t += PRE_BLOCK) im.tile_order[t] = (uint32_t)t;
   }
@@ -435,107 +429,152 @@ __device__ void frame_scan(int nblk, int tiles, int capacity, uint32_t *block_su
 }
 
 // ---- instance scatter ----------------------------------------------------------------------------------------------
-// Every Gaussian drops (depth bits << 32 | id) into a free slot of each touched tile's list segment (duplicateWithKeys,
-// rasterizer_impl.cu:70-111, without the tile id in the key: the segments are the tiles).  Slot order inside a tile is
-// arbitrary; the tile sort orders by (depth, id), a total order, so the final lists are deterministic.
+// Every Gaussian drops its id into a free slot of each touched tile's list segment (duplicateWithKeys,
+// rasterizer_impl.cu:70-111; the segments are the tiles, and the depth half of the reference's key is gathered by the tile
+// sort from the 4-byte depth array, which stays in L2: half the scattered bytes).  Slot order inside a tile is arbitrary;
+// the tile sort orders by (depth, id), a total order, so the final lists are deterministic.
 //
-// Who writes what (MI355X: 8 XCDs, each with its own L2 that writes partial lines back on its own).  A tile's segment is a
-// few hundred contiguous 8-byte keys; written by workgroups of all eight XCDs, every 128-byte line of it left eight L2s in
-// pieces (WRITE_SIZE 4x the bytes, profiles/r02_pmc_summary.json).  So the tile ROWS are dealt into SCAT_CLS = 8 classes
-// (row y belongs to class y % 8) and a workgroup emits only its class: blockIdx.x % 8 = class = the XCD the dispatcher is
-// observed to put the workgroup on (speed only -- any placement gives the same lists), so one L2 assembles a segment's
-// lines.  The workgroup covers SCAT_GPT x 256 Gaussians (eight workgroups, one per class, read the same 16-byte `scat`
-// entries): per tile of its class it counts in LDS, reserves ONE slot range with a returning global atomic (1/5 of the
-// atomics a 256-Gaussian workgroup over all tiles needed, and runs of ~13 keys instead of ~2), then hands the slots out
-// with LDS atomics.
+// Who writes what (MI355X: 8 XCDs, each with its own L2 that writes partial lines back on its own, in 64-byte pieces).  A
+// tile's segment is a few hundred contiguous ids; written by 256-Gaussian workgroups of all eight XCDs, two ids at a time,
+// it left the L2s as 4x its bytes (WRITE_SIZE, profiles/r02_pmc_summary.json).  So the tile ROWS are dealt into
+// SCAT_CLS = 8 classes (row y belongs to class y % 8) and a workgroup emits only its class: blockIdx.x % 8 = class = the XCD
+// the dispatcher is observed to put the workgroup on (speed only -- any placement gives the same lists), so one L2 assembles
+// a segment's lines.  The workgroup covers gpt x 256 Gaussians (eight workgroups, one per class, read the same 8-byte `scat`
+// entries; gpt grows with the launch -- launch_tile_binning -- so that a workgroup leaves tens of ids per tile: the run a
+// workgroup appends to a segment is what leaves L2 in one piece): per tile of its class it counts in LDS, reserves ONE slot
+// range with a returning global atomic, then hands the slots out with LDS atomics -- into an LDS staging area ordered by
+// tile, which the workgroup then writes out with consecutive lanes on consecutive slots of a run.  (Stored straight from the
+// hand-out loop every lane of a store instruction hit a different tile: 64 separate transactions per instruction, and the
+// store phase was half of a wave's life -- tools/batch_trace.py.)
 #ifndef SCAT_CLS
 #define SCAT_CLS 8
 #endif
-#ifndef SCAT_GPT
-#define SCAT_GPT 8
-#endif
-#define SCAT_LDS_TILES 8192  // class-local tiles the LDS counters hold (64 KB); more: direct global atomics
+#define SCAT_LDS_TILES 4096  // class-local tiles the LDS counters hold (3 words each: 48 KB); more: direct global atomics
+#define SCAT_STAGE 4096      // instances a workgroup stages in LDS before writing them out (32 KB); more: stored directly
 GSAJ_TRACE_DEFINE(scat)
 
-__global__ __launch_bounds__(PRE_BLOCK) void k_scatter_instances(int P, int gx, int gy, GeomWS g, ImageWS im,
-                                                                 uint64_t *__restrict__ inst_key, ViewStrides vs) {
-  extern __shared__ uint32_t lds[];  // [2 * ltiles]: count -> reserved base, fill cursor (class-local tile index)
+__global__ __launch_bounds__(PRE_BLOCK) void k_scatter_instances(int P, int gx, int gy, int gpt, GeomWS g, ImageWS im,
+                                                                 uint32_t *__restrict__ inst_id, ViewStrides vs) {
+  extern __shared__ uint32_t lds[];  // [3 * ltiles]: count -> reserved base, fill cursor, staging base (class-local tile index)
+  __shared__ uint32_t stage_id[SCAT_STAGE], stage_slot[SCAT_STAGE];
+  __shared__ uint32_t s_wave[PRE_BLOCK / 64], s_carry;
   {
     const size_t view = blockIdx.y;
     g = geom_view(g, view * vs.geom);
     im = image_view(im, view * vs.image);
-    inst_key = gsaj_shift(inst_key, view * vs.bin);
+    inst_id = gsaj_shift(inst_id, view * vs.bin);
   }
   if (im.counters[4]) return;  // aborted async frame
   GSAJ_TRACE_BEGIN(scat)
+#ifdef GSAJ_BLOCK_TRACE
+  unsigned long long trs_[4] = {0, 0, 0, 0}, trs_t = wall_clock64();
+#define TRS(i) { const unsigned long long n_ = wall_clock64(); trs_[i] += n_ - trs_t; trs_t = n_; }
+#else
+#define TRS(i)
+#endif
   const int tid = threadIdx.x;
   const int cls = (int)(blockIdx.x % SCAT_CLS), gb = (int)(blockIdx.x / SCAT_CLS);
   const int rows_c = (gy - cls + SCAT_CLS - 1) / SCAT_CLS;  // tile rows y = cls + SCAT_CLS * j < gy
   const int ltiles = rows_c > 0 ? rows_c * gx : 0;
   const bool use_lds = ((gy + SCAT_CLS - 1) / SCAT_CLS) * gx <= SCAT_LDS_TILES;
-  uint32_t *cnt = lds, *fill = lds + ltiles;
+  uint32_t *cnt = lds, *fill = lds + ltiles, *lbase = lds + 2 * ltiles;
   if (use_lds) {
     for (int t = tid; t < 2 * ltiles; t += PRE_BLOCK) lds[t] = 0u;
+    if (tid == 0) s_carry = 0u;
     __syncthreads();
   }
-  // this thread's Gaussians: all requested up front
-  uint4 sc[SCAT_GPT];
-#pragma unroll
-  for (int i = 0; i < SCAT_GPT; i++) {
-    const int idx = (gb * SCAT_GPT + i) * PRE_BLOCK + tid;
-    sc[i] = idx < P ? g.scat[idx] : make_uint4(0u, 0u, 0u, 0u);
-  }
-  // rows of this class inside [y0, y1): y = ys, ys + SCAT_CLS, ...
+  // this workgroup's Gaussians: (gb * gpt + i) * 256 + tid, i < gpt -- four rectangles requested at a time; the second walk
+  // finds them in L2.  Rows of this class inside [y0, y1): y = ys, ys + SCAT_CLS, ...
 #define SCAT_FOR_EACH_TILE(BODY)                                                                     \
-  _Pragma("unroll") for (int i = 0; i < SCAT_GPT; i++) {                                             \
-    const int x0 = (int)(sc[i].y & 0xffffu), x1 = (int)(sc[i].y >> 16);                             \
-    const int y0 = (int)(sc[i].z & 0xffffu), y1 = (int)(sc[i].z >> 16);                             \
-    if (x1 > x0) {                                                                                   \
-      const int idx = (gb * SCAT_GPT + i) * PRE_BLOCK + tid;                                         \
-      const uint64_t key = ((uint64_t)sc[i].x << 32) | (uint32_t)idx;                                \
-      (void)key;                                                                                     \
-      const int ys = y0 + ((cls - y0) % SCAT_CLS + SCAT_CLS) % SCAT_CLS;                             \
-      for (int y = ys; y < y1; y += SCAT_CLS)                                                        \
-        for (int x = x0; x < x1; x++) {                                                              \
-          const int lt = (y / SCAT_CLS) * gx + x; /* class-local tile */                             \
-          const int t = y * gx + x;               /* tile */                                         \
-          (void)lt; (void)t;                                                                         \
-          BODY                                                                                       \
-        }                                                                                            \
+  for (int i0 = 0; i0 < gpt; i0 += 4) {                                                              \
+    uint2 sc[4];                                                                                     \
+    _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                  \
+      const int idx = (gb * gpt + i0 + j) * PRE_BLOCK + tid;                                         \
+      sc[j] = (i0 + j < gpt && idx < P) ? g.scat[idx] : make_uint2(0u, 0u);                          \
+    }                                                                                                \
+    _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                  \
+      const int x0 = (int)(sc[j].x & 0xffffu), x1 = (int)(sc[j].x >> 16);                            \
+      const int y0 = (int)(sc[j].y & 0xffffu), y1 = (int)(sc[j].y >> 16);                            \
+      if (x1 > x0) {                                                                                 \
+        const uint32_t id = (uint32_t)((gb * gpt + i0 + j) * PRE_BLOCK + tid);                       \
+        (void)id;                                                                                    \
+        const int ys = y0 + ((cls - y0) % SCAT_CLS + SCAT_CLS) % SCAT_CLS;                           \
+        for (int y = ys; y < y1; y += SCAT_CLS)                                                      \
+          for (int x = x0; x < x1; x++) {                                                            \
+            const int lt = (y / SCAT_CLS) * gx + x; /* class-local tile */                           \
+            const int t = y * gx + x;               /* tile */                                       \
+            (void)lt; (void)t;                                                                       \
+            BODY                                                                                     \
+          }                                                                                          \
+      }                                                                                              \
     }                                                                                                \
   }
   if (!use_lds) {  // (more than 8 x 8192 tiles: beyond 16 384 x 2048 pixels)
-    SCAT_FOR_EACH_TILE({ inst_key[im.tile_offset[t] + atomicAdd(&im.tile_cursor[t], 1u)] = key; })
+    SCAT_FOR_EACH_TILE({ inst_id[im.tile_offset[t] + atomicAdd(&im.tile_cursor[t], 1u)] = id; })
     return;
   }
+  TRS(0)
   SCAT_FOR_EACH_TILE({ atomicAdd(&cnt[lt], 1u); })
   __syncthreads();
-  // reserve this workgroup's slot range in every tile of its class it touches: returning atomics, eight to a batch so
-  // that their round trips overlap (one s_waitcnt per batch instead of one per tile)
-  for (int l0 = 0; l0 < ltiles; l0 += 8 * PRE_BLOCK) {
-    uint32_t c[8], base[8], off[8];
-#pragma unroll
-    for (int b = 0; b < 8; b++) {
-      const int lt = l0 + b * PRE_BLOCK + tid;
-      c[b] = 0u, off[b] = 0u, base[b] = 0u;
-      if (lt < ltiles) {
-        const int j = lt / gx;
-        const int t = (j * SCAT_CLS + cls) * gx + (lt - j * gx);
-        c[b] = cnt[lt];
-        off[b] = im.tile_offset[t];  // in flight together with the atomics
-        if (c[b]) base[b] = atomicAdd(&im.tile_cursor[t], c[b]);
-      }
+  TRS(1)
+  // reserve this workgroup's slot range in every tile of its class it touches (returning atomics, their round trips
+  // overlapping across the lanes) and lay the tiles' runs out back to back in the staging area: 256 tiles per step, exclusive
+  // scan of their counts by wave shuffles + one LDS hop, carry from step to step
+  for (int l0 = 0; l0 < ltiles; l0 += PRE_BLOCK) {
+    const int lt = l0 + tid, lane = tid & 63;
+    uint32_t c = 0u, off = 0u, base = 0u;
+    if (lt < ltiles) {
+      const int j = lt / gx;
+      const int t = (j * SCAT_CLS + cls) * gx + (lt - j * gx);
+      c = cnt[lt];
+      off = im.tile_offset[t];  // in flight together with the atomic
+      if (c) base = atomicAdd(&im.tile_cursor[t], c);
     }
+    uint32_t incl = c;
 #pragma unroll
-    for (int b = 0; b < 8; b++) {
-      const int lt = l0 + b * PRE_BLOCK + tid;
-      if (c[b]) cnt[lt] = off[b] + base[b];
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
+      if (lane >= o) incl += v;
     }
+    if (lane == 63) s_wave[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t before = s_carry;
+#pragma unroll
+    for (int w = 0; w < PRE_BLOCK / 64; w++)
+      if (w < (tid >> 6)) before += s_wave[w];
+    if (lt < ltiles) {
+      cnt[lt] = off + base;
+      lbase[lt] = before + incl - c;
+    }
+    __syncthreads();
+    if (tid == PRE_BLOCK - 1) s_carry = before + incl;
   }
   __syncthreads();
-  SCAT_FOR_EACH_TILE({ inst_key[cnt[lt] + atomicAdd(&fill[lt], 1u)] = key; })
+  const uint32_t total = s_carry;  // this workgroup's instances
+  TRS(2)
+  if (total <= SCAT_STAGE) {
+    SCAT_FOR_EACH_TILE({
+      const uint32_t k = atomicAdd(&fill[lt], 1u);
+      stage_id[lbase[lt] + k] = id;
+      stage_slot[lbase[lt] + k] = cnt[lt] + k;
+    })
+    __syncthreads();
+    for (uint32_t i = tid; i < total; i += PRE_BLOCK) inst_id[stage_slot[i]] = stage_id[i];
+  } else {  // (large Gaussians: more instances than the staging area holds)
+    SCAT_FOR_EACH_TILE({ inst_id[cnt[lt] + atomicAdd(&fill[lt], 1u)] = id; })
+  }
 #undef SCAT_FOR_EACH_TILE
+  TRS(3)
   GSAJ_TRACE_END(scat)
+#ifdef GSAJ_BLOCK_TRACE
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned tw_ = (blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (tw_ < GSAJ_TRACE_MAX) {
+      g_trace_scat[4 * tw_ + 2] = (trs_[0] << 32) | trs_[1];
+      g_trace_scat[4 * tw_ + 3] = (trs_[2] << 32) | trs_[3];
+    }
+  }
+#endif
 }
 
 // fp16-storage rows (GSAJ_FWD_RECORDS_FP16): conic / opacity / colour of every Gaussian rounded to half ONCE, here; mean2D,
@@ -649,16 +688,24 @@ __device__ __forceinline__ void lds_bitonic_sort(uint64_t *keys, int m, int tid)
 }
 
 // A tile list longer than the LDS holds (n > T keys; the reference's global radix sort takes any length,
-// rasterizer_impl.cu:353-368).  (1) chunks of T keys are sorted in LDS, a -> b; (2) merge passes b -> a -> b ... over runs of
+// rasterizer_impl.cu:353-368).  (1) chunks of T keys (ids + gathered depths) are sorted in LDS -> b; (2) merge passes b -> a -> b ... over runs of
 // T, 2T, ...: the output of a pair of runs is produced T keys at a time -- the merge-path split of every T-th output
 // diagonal is found by binary search (one thread per diagonal), the two input pieces (together T keys) are loaded as
 // [A ascending | +inf | B descending], a bitonic sequence that ONE merge level sorts.  Everything inside the tile's own
 // workgroup and key segment; returns the buffer that holds the sorted keys.
-__device__ const uint64_t *sort_long_list(uint64_t *lds, int T, uint64_t *a, uint64_t *b, int n, int tid) {
+__device__ const uint64_t *sort_long_list(uint64_t *lds, int T, const uint32_t *ids, const float *__restrict__ depths, uint64_t *a,
+                                          uint64_t *b, int n, int tid) {
   __shared__ uint32_t split_s[PRE_BLOCK + 1];
   for (int c0 = 0; c0 < n; c0 += T) {
     const int len = min(T, n - c0);
-    for (int i = tid; i < T; i += 256) lds[i] = i < len ? a[c0 + i] : ~0ull;
+    for (int i = tid; i < T; i += 256) {
+      uint64_t key = ~0ull;
+      if (i < len) {
+        const uint32_t id = ids[c0 + i];
+        key = ((uint64_t)__float_as_uint(depths[id]) << 32) | id;
+      }
+      lds[i] = key;
+    }
     __syncthreads();
     lds_bitonic_sort(lds, T, tid);
     for (int i = tid; i < len; i += 256) b[c0 + i] = lds[i];
@@ -712,16 +759,17 @@ __device__ const uint64_t *sort_long_list(uint64_t *lds, int T, uint64_t *a, uin
   return src;
 }
 
-// One workgroup per tile: sort of the tile's (depth, id) keys -> the sorted Gaussian ids (point_list) and the tile's [start, end)
+// One workgroup per tile: sort of the tile's (depth, id) keys -> the sorted Gaussian ids (point_list, in place) and the tile's [start, end)
 // range (cub::DeviceRadixSort + identifyTileRanges, rasterizer_impl.cu:353-368, 116-138); the tile's `reached` flags cleared.
 GSAJ_TRACE_DEFINE(sort)
 
-__global__ __launch_bounds__(256) void k_tile_sort(ImageWS im, uint64_t *__restrict__ inst_key, uint64_t *__restrict__ keys_b,
-                                                   uint32_t *__restrict__ point_list, uint8_t *__restrict__ reached, int cap,
-                                                   int pass, int rec16, ViewStrides vs) {
+__global__ __launch_bounds__(256) void k_tile_sort(ImageWS im, const float *__restrict__ depths, uint64_t *__restrict__ inst_key,
+                                                   uint64_t *__restrict__ keys_b, uint32_t *point_list,
+                                                   uint8_t *__restrict__ reached, int cap, int pass, int rec16, ViewStrides vs) {
   {
     const size_t view = blockIdx.y;
     im = image_view(im, view * vs.image);
+    depths = gsaj_shift(depths, view * vs.geom);
     inst_key = gsaj_shift(inst_key, view * vs.bin);
     keys_b = gsaj_shift(keys_b, view * vs.bin);
     point_list = gsaj_shift(point_list, view * vs.bin);
@@ -753,13 +801,21 @@ __global__ __launch_bounds__(256) void k_tile_sort(ImageWS im, uint64_t *__restr
   const uint64_t *sorted = keys;
   if (n > cap) {
     if (pass == 2) return;  // (pass 2 has half of pass 1's LDS: pass 1 took it)
-    sorted = sort_long_list(keys, cap, inst_key + beg, keys_b + beg, n, tid);
+    sorted = sort_long_list(keys, cap, point_list + beg, depths, inst_key + beg, keys_b + beg, n, tid);
   } else {
     int m = 2;
     while (m < n) m <<= 1;
     if (pass == 1 && 2 * m <= cap) return;  // pass 2's
     if (pass == 2 && m > cap) return;       // pass 1's (here cap = half of pass 1's)
-    for (int i = tid; i < m; i += 256) keys[i] = i < n ? inst_key[beg + i] : ~0ull;
+    // the tile's ids as scattered (point_list, sorted in place below) + their depths gathered from the 4-byte depth array (L2)
+    for (int i = tid; i < m; i += 256) {
+      uint64_t key = ~0ull;
+      if (i < n) {
+        const uint32_t id = point_list[beg + i];
+        key = ((uint64_t)__float_as_uint(depths[id]) << 32) | id;
+      }
+      keys[i] = key;
+    }
     __syncthreads();
 #ifdef GSAJ_BLOCK_TRACE
     tr_b = wall_clock64();
@@ -810,6 +866,7 @@ int launch_preprocess(const FwdParams &p, int *radii, int *n_touched, const Geom
     const int tiles = p.grid_x * p.grid_y;
     const size_t lds = tiles <= LDS_TILES_MAX ? sizeof(uint32_t) * (size_t)tiles : 0;
     hipLaunchKernelGGL(k_preprocess, dim3(nblk, views), dim3(PRE_BLOCK), lds, s, p, radii, n_touched, g, im, vs);
+    hipLaunchKernelGGL(k_frame_scan, dim3(1, views), dim3(PRE_BLOCK), lds, s, nblk, tiles, p.capacity, g, im, vs);
   }
   GSAJ_HIP_CHECK(hipGetLastError());
   return GSAJ_OK;
@@ -820,10 +877,15 @@ int launch_tile_binning(int P, int sort_cap, int rec16, int grid_x, int grid_y, 
   {
     GsajProfScope ps(ST_SCATTER, s);
     const int ltiles = ((grid_y + SCAT_CLS - 1) / SCAT_CLS) * grid_x;
-    const size_t lds = ltiles <= SCAT_LDS_TILES ? 2 * sizeof(uint32_t) * (size_t)ltiles : 0;
-    const int per = PRE_BLOCK * SCAT_GPT;
+    const size_t lds = ltiles <= SCAT_LDS_TILES ? 3 * sizeof(uint32_t) * (size_t)ltiles : 0;
+    // Gaussians per thread: as many as still leave ~1500 workgroups in the launch (4 .. 8; 8 x 256 Gaussians put ~2000-3000
+    // instances of one class into the 4096-entry staging area): the longer a workgroup's run of ids per tile, the fewer partial
+    // 64-byte pieces leave L2
+    int gpt = 4;
+    while (gpt < 8 && (long long)P * views * SCAT_CLS / ((long long)PRE_BLOCK * gpt * 2) >= 1536) gpt *= 2;
+    const int per = PRE_BLOCK * gpt;
     hipLaunchKernelGGL(k_scatter_instances, dim3((unsigned)((P + per - 1) / per) * SCAT_CLS, views), dim3(PRE_BLOCK), lds, s, P, grid_x,
-                       grid_y, g, im, b.keys_unsorted, vs);
+                       grid_y, gpt, g, im, b.point_list, vs);
     if (rec16)
       hipLaunchKernelGGL(k_pack_splat16, dim3((P + 255) / 256, views), dim3(256), 0, s, P, g, im.counters, vs);
   }
@@ -835,13 +897,13 @@ int launch_tile_binning(int P, int sort_cap, int rec16, int grid_x, int grid_y, 
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_sort), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(sizeof(uint64_t) * (size_t)cap));
     if (cap >= 4096) {
-      hipLaunchKernelGGL(k_tile_sort, dim3(grid_x * grid_y, views), dim3(256), sizeof(uint64_t) * (size_t)cap, s, im, b.keys_unsorted,
-                         b.keys, b.point_list, b.reached, cap, 1, rec16, vs);
-      hipLaunchKernelGGL(k_tile_sort, dim3(grid_x * grid_y, views), dim3(256), sizeof(uint64_t) * (size_t)(cap / 2), s, im,
+      hipLaunchKernelGGL(k_tile_sort, dim3(grid_x * grid_y, views), dim3(256), sizeof(uint64_t) * (size_t)cap, s, im, g.depths,
+                         b.keys_unsorted, b.keys, b.point_list, b.reached, cap, 1, rec16, vs);
+      hipLaunchKernelGGL(k_tile_sort, dim3(grid_x * grid_y, views), dim3(256), sizeof(uint64_t) * (size_t)(cap / 2), s, im, g.depths,
                          b.keys_unsorted, b.keys, b.point_list, b.reached, cap / 2, 2, rec16, vs);
     } else {
-      hipLaunchKernelGGL(k_tile_sort, dim3(grid_x * grid_y, views), dim3(256), sizeof(uint64_t) * (size_t)cap, s, im, b.keys_unsorted,
-                         b.keys, b.point_list, b.reached, cap, 0, rec16, vs);
+      hipLaunchKernelGGL(k_tile_sort, dim3(grid_x * grid_y, views), dim3(256), sizeof(uint64_t) * (size_t)cap, s, im, g.depths,
+                         b.keys_unsorted, b.keys, b.point_list, b.reached, cap, 0, rec16, vs);
     }
   }
   GSAJ_HIP_CHECK(hipGetLastError());

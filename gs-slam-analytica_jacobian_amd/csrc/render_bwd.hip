@@ -134,8 +134,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
       const uint32_t blk_first = g.block_sums[id / PRE_BLOCK];  // exclusive offset of the Gaussian's block (frame scan)
       uint32_t x0, y0, w;
       if (rec16) {
-        const uint4 sc = g.scat[id];
-        x0 = sc.y & 0xffffu, y0 = sc.z & 0xffffu, w = (sc.y >> 16) - x0;
+        const uint2 sc = g.scat[id];
+        x0 = sc.x & 0xffffu, y0 = sc.y & 0xffffu, w = (sc.x >> 16) - x0;
       } else {
         const uint32_t rp = __float_as_uint(q2.w);
         x0 = rp & 1023u, y0 = (rp >> 10) & 1023u, w = rp >> 20;

@@ -56,13 +56,13 @@ def main():
                  *np.percentile((e - t0) * 0.01, [50, 95, 99]), busy))
         first = int(((s - t0) * 0.01 < 3.0).sum())
         print("      resident at once (waves started within the first 3 us): %d" % first)
-        if name == "pre":  # phase stamps (indexed by workgroup only: one view's, whichever wrote last)
-            nb = ((P + 255) // 256) * 4
+        if name in ("pre", "scat"):  # phase stamps (pre: indexed by workgroup only -- one view's, whichever wrote last)
+            nb = ((P + 255) // 256) * 4 if name == "pre" else n
             raw = np.zeros((nb, 4), np.uint64)
             fn(raw.ctypes.data, nb)
             lo32 = np.uint64(0xffffffff)
             ph = [raw[:, 2] >> np.uint64(32), raw[:, 2] & lo32, raw[:, 3] >> np.uint64(32), raw[:, 3] & lo32]
-            labels = {"pre": "per-Gaussian work / histogram flush + block scan / drain + ticket / frame scan (last workgroup)",
+            labels = {"pre": "per-Gaussian work / histogram flush + block scan / - / -",
                       "scat": "zero LDS + loads / LDS count / reserve (returning atomics) / stores"}[name]
             print("      phases (us, mean): %s = %s" % (labels, " / ".join("%.1f" % (x.astype(np.int64).mean() * 0.01) for x in ph)))
 
