@@ -202,6 +202,16 @@ int gsaj_forward_aborted_count(int W, int H, void *image_ws, void *stream, int *
   return GSAJ_OK;
 }
 
+const uint32_t *gsaj_forward_abort_flag(int W, int H, void *image_ws) {
+  if (W <= 0 || H <= 0 || !image_ws) {
+    gsaj_set_error("gsaj_forward_abort_flag: invalid argument");
+    return nullptr;
+  }
+  ImageWS im;
+  image_carve(align_base(image_ws), W, H, &im);
+  return im.counters + 4;
+}
+
 int gsaj_set_tile_band(int W, int H, void *image_ws, int tile_row_begin, int tile_row_end, void *stream) {
   const int gy = (H + TILE - 1) / TILE;
   if (W <= 0 || H <= 0 || !image_ws || tile_row_begin < 0 || tile_row_end < tile_row_begin || tile_row_end > gy || gy > 0xffff) {
@@ -524,6 +534,17 @@ int gsaj_debug_export(int P, int R, int W, int H, const void *geom_ws, const voi
     CP(n_contrib, im.n_contrib, sizeof(uint32_t) * N);
   }
 #undef CP
+  return GSAJ_OK;
+}
+
+int gsaj_debug_export_view_sums(int P, const void *geom_ws, float *sums, void *stream) {
+  if (P <= 0 || !geom_ws || !sums) {
+    gsaj_set_error("gsaj_debug_export_view_sums: invalid argument");
+    return GSAJ_ERR_INVALID_ARGUMENT;
+  }
+  GeomWS g;
+  geom_carve(align_base(const_cast<void *>(geom_ws)), (size_t)P, &g);
+  GSAJ_HIP_CHECK(hipMemcpyAsync(sums, g.gsum, sizeof(float4) * 3 * (size_t)P, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return GSAJ_OK;
 }
 

@@ -28,6 +28,8 @@ struct PoseStepParams {
   float beta1, beta2, eps, threshold;
   float *st;
   const uint8_t *active;  // batched launch: per-pose enable flags (NULL: all)
+  const uint32_t *skip;   // (may be NULL) a non-zero word makes the step a no-op: the frame's abort flag (gsaj_forward_abort_flag),
+  size_t skip_stride;     //   pose k's word `skip_stride` bytes after pose k - 1's
 };
 
 __device__ void so3_exp_and_v(const float *th, float R[9], float V[9]) {
@@ -58,6 +60,9 @@ __global__ void k_pose_adam_step(PoseStepParams p) {
   // batched launch: workgroup k steps pose k ([K,6] gradients, [K,2] exposure gradients, K states); `active` (may be NULL) masks
   // keyframes whose pose stays fixed (the reference skips uid 0, utils/slam_backend.py:255-258)
   if (p.active && !p.active[blockIdx.x]) return;
+  // the frame these gradients belong to was aborted on the device (its kernels returned at once: dL/dtau and the loss terms are
+  // the PREVIOUS iteration's): Adam must not step on them, nor advance its moments
+  if (p.skip && *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(p.skip) + p.skip_stride * blockIdx.x) != 0u) return;
   p.g_tau += 6 * (size_t)blockIdx.x;
   if (p.g_exp) p.g_exp += 2 * (size_t)blockIdx.x;
   float *st = p.st + (size_t)GSAJ_POSE_STATE_FLOATS * blockIdx.x;
@@ -124,7 +129,7 @@ extern "C" int gsaj_pose_state_floats(void) { return GSAJ_POSE_STATE_FLOATS; }
 
 extern "C" int gsaj_pose_adam_step(const float *dL_dtau, const float *dL_dexposure, float lr_rot, float lr_trans, float lr_exp_a,
                                    float lr_exp_b, float beta1, float beta2, float eps, float converged_threshold,
-                                   const float *projection_matrix, float *pose_state, void *stream) {
+                                   const float *projection_matrix, float *pose_state, const uint32_t *skip, void *stream) {
   if (!dL_dtau || !pose_state) {
     gsaj_set_error("gsaj_pose_adam_step: dL_dtau and pose_state are required");
     return GSAJ_ERR_INVALID_ARGUMENT;
@@ -136,6 +141,7 @@ extern "C" int gsaj_pose_adam_step(const float *dL_dtau, const float *dL_dexposu
   p.beta1 = beta1; p.beta2 = beta2; p.eps = eps; p.threshold = converged_threshold;
   p.st = pose_state;
   p.active = nullptr;
+  p.skip = skip; p.skip_stride = 0;
   hipLaunchKernelGGL(k_pose_adam_step, dim3(1), dim3(64), 0, (hipStream_t)stream, p);
   GSAJ_HIP_CHECK(hipGetLastError());
   return GSAJ_OK;
@@ -144,7 +150,7 @@ extern "C" int gsaj_pose_adam_step(const float *dL_dtau, const float *dL_dexposu
 extern "C" int gsaj_pose_adam_step_batch(int K, const float *dL_dtau, const float *dL_dexposure, const uint8_t *active, float lr_rot,
                                          float lr_trans, float lr_exp_a, float lr_exp_b, float beta1, float beta2, float eps,
                                          float converged_threshold, const float *projection_matrix, float *pose_states,
-                                         void *stream) {
+                                         const uint32_t *skip, size_t skip_stride_bytes, void *stream) {
   if (K <= 0 || !dL_dtau || !pose_states) {
     gsaj_set_error("gsaj_pose_adam_step_batch: K > 0, dL_dtau and pose_states are required");
     return GSAJ_ERR_INVALID_ARGUMENT;
@@ -156,6 +162,7 @@ extern "C" int gsaj_pose_adam_step_batch(int K, const float *dL_dtau, const floa
   p.beta1 = beta1; p.beta2 = beta2; p.eps = eps; p.threshold = converged_threshold;
   p.st = pose_states;
   p.active = active;
+  p.skip = skip; p.skip_stride = skip_stride_bytes;
   hipLaunchKernelGGL(k_pose_adam_step, dim3((unsigned)K), dim3(64), 0, (hipStream_t)stream, p);
   GSAJ_HIP_CHECK(hipGetLastError());
   return GSAJ_OK;

@@ -125,11 +125,25 @@ class GaussianModel:
         from gsaj.model_io import read_parameter_tensors
         try:
             ts = read_parameter_tensors(model_path)
-            if len(ts) < 6:
-                raise ValueError("expected 6 parameter tensors, found %d" % len(ts))
-            xyz, f_dc, f_rest, opacity, scaling, rotation = ts[:6]
+            # the reference takes named_parameters() of the scripted module (parameters only, in registration order); the
+            # restricted reader returns every tensor of the pickled state in stored order and does NOT tell parameters from
+            # buffers, so the six must be exactly six and must look like xyz, f_dc, f_rest, opacity, scaling, rotation -- an
+            # archive with anything else in between would otherwise be mapped to the wrong fields without a word
+            if len(ts) != 6:
+                raise ValueError("expected exactly 6 parameter tensors (xyz, f_dc, f_rest, opacity, scaling, rotation), found %d" % len(ts))
+            xyz, f_dc, f_rest, opacity, scaling, rotation = ts
             if f_dc.dim() == 2:
                 f_dc = f_dc.unsqueeze(1)
+            P = xyz.shape[0] if xyz.dim() == 2 else -1
+            ok = (all(t.is_floating_point() for t in ts) and xyz.dim() == 2 and xyz.shape[1] == 3
+                  and f_dc.dim() == 3 and tuple(f_dc.shape[::2]) == (P, 3) and f_dc.shape[1] == 1
+                  and f_rest.dim() == 3 and tuple(f_rest.shape[::2]) == (P, 3)
+                  and tuple(opacity.shape) == (P, 1)
+                  and scaling.dim() == 2 and scaling.shape[0] == P and scaling.shape[1] in (1, 3)
+                  and tuple(rotation.shape) == (P, 4))
+            if not ok:
+                raise ValueError("the 6 tensors do not have the shapes of (xyz [P,3], f_dc [P,1,3], f_rest [P,M-1,3], opacity [P,1], "
+                                 "scaling [P,1|3], rotation [P,4]): %s" % ([tuple(t.shape) for t in ts],))
             self._set_params(xyz, f_dc, f_rest, opacity, scaling, rotation, device)
             return True
         except Exception as e:  # noqa: BLE001 -- the reference reports and returns False

@@ -44,6 +44,7 @@ SIGNATURES = {
                                         c_float, c_float, P, P, P, P, P, P] + [P] * 12 + [P]),
     "gsaj_mark_visible": (c_int, [c_int, P, P, P, P, P]),
     "gsaj_debug_export": (c_int, [c_int] * 4 + [P] * 3 + [P] * 11 + [P]),
+    "gsaj_debug_export_view_sums": (c_int, [c_int, P, P, P]),
     "gsaj_profile_begin": (c_int, [c_int]),
     "gsaj_profile_end": (c_int, [P, P]),
     "gsaj_dense_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
@@ -56,8 +57,9 @@ SIGNATURES = {
     "gsaj_dist2_workspace_bytes": (c_size_t, [c_int]),
     "gsaj_dist2": (c_int, [c_int, P, P, P, P]),
     "gsaj_pose_state_floats": (c_int, []),
-    "gsaj_pose_adam_step": (c_int, [P, P] + [c_float] * 8 + [P, P, P]),
-    "gsaj_pose_adam_step_batch": (c_int, [c_int, P, P, P] + [c_float] * 8 + [P, P, P]),
+    "gsaj_pose_adam_step": (c_int, [P, P] + [c_float] * 8 + [P, P, P, P]),
+    "gsaj_pose_adam_step_batch": (c_int, [c_int, P, P, P] + [c_float] * 8 + [P, P, P, c_size_t, P]),
+    "gsaj_forward_abort_flag": (c_void_p, [c_int, c_int, P]),
     "gsaj_loss_workspace_bytes": (c_size_t, [c_int, c_int]),
     "gsaj_densification_stats": (c_int, [c_int, c_int] + [P] * 7 + [P]),
     "gsaj_isotropic_workspace_bytes": (c_size_t, [c_int]),

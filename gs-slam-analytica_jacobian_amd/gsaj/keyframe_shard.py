@@ -58,6 +58,33 @@ def allreduce_gaussian_grads(bucket, group=None, async_op=False):
     return None if async_op else bucket
 
 
+def exchange_gaussian_grads(bucket, form="all_reduce", group=None):
+    """Blocking sum of the bucket over the ranks, in one of two forms with the same result:
+      "all_reduce"                  one all-reduce (what the training step uses, asynchronously);
+      "reduce_scatter+all_gather"   each rank first receives the sum of ITS 1/world slice, then the slices are gathered --
+                                    the two halves of a ring all-reduce as separate collectives (on point-to-point
+                                    xGMI both halves can keep all seven links of a GPU busy).  The bucket is padded to a
+                                    multiple of the world size in a scratch tensor.  Backends without reduce-scatter (gloo)
+                                    raise RuntimeError."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return bucket
+    if form == "all_reduce":
+        dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
+        return bucket
+    if form != "reduce_scatter+all_gather":
+        raise ValueError("unknown form %r" % (form,))
+    world = dist.get_world_size(group)
+    n = bucket.numel()
+    per = (n + world - 1) // world
+    full = bucket if per * world == n else torch.cat([bucket, bucket.new_zeros(per * world - n)])
+    shard = torch.empty(per, dtype=bucket.dtype, device=bucket.device)
+    dist.reduce_scatter_tensor(shard, full, op=dist.ReduceOp.SUM, group=group)
+    dist.all_gather_into_tensor(full, shard, group=group)
+    if full is not bucket:
+        bucket.copy_(full[:n])
+    return bucket
+
+
 def gather_pose_grads(tau_local, n_keyframes, group=None):
     """tau_local: [k_local, 6] in the order of shard_keyframes(); returns [n_keyframes, 6] with
     row k = dL/dtau of keyframe k on every rank.  Ranks may own different numbers of keyframes:

@@ -54,15 +54,17 @@ class PoseTracker:
     tau = property(lambda s: s._v("tau"))
     converged = property(lambda s: s.state[77])                   # device scalar: 1.0 when |tau| < threshold
 
-    def step(self, dL_dtau_sum, dL_dexposure=None):
-        """dL_dtau_sum: device float32 [6] = [rho, theta] (gsaj_rasterize_backward); dL_dexposure: device [2] or None."""
+    def step(self, dL_dtau_sum, dL_dexposure=None, skip=None):
+        """dL_dtau_sum: device float32 [6] = [rho, theta] (gsaj_rasterize_backward); dL_dexposure: device [2] or None.
+        skip: device address (int) of a 32-bit word, or None: non-zero when the gradients are stale because their frame was aborted
+        on the device (FrameContext.abort_flag_ptr) -- the step then changes nothing."""
         for t in (dL_dtau_sum, dL_dexposure):
             if t is not None and (t.device.type != "cuda" or t.dtype != torch.float32 or not t.is_contiguous()):
                 raise _lib.GsajError("gradients must be contiguous float32 device tensors")
         st = torch.cuda.current_stream(self.dev).cuda_stream
         _lib.check(self.lib.gsaj_pose_adam_step(dL_dtau_sum.data_ptr(), None if dL_dexposure is None else dL_dexposure.data_ptr(),
                                                 self.lr[0], self.lr[1], self.lr[2], self.lr[3], self.betas[0], self.betas[1], self.eps,
-                                                self.thr, self.projection.data_ptr(), self.state.data_ptr(), st),
+                                                self.thr, self.projection.data_ptr(), self.state.data_ptr(), skip, st),
                    "gsaj_pose_adam_step")
 
 
@@ -85,8 +87,9 @@ class PoseTrackerBatch:
         self.lr, self.betas, self.eps, self.thr = self.singles[0].lr, self.singles[0].betas, self.singles[0].eps, self.singles[0].thr
         del self.singles
 
-    def step(self, dL_dtau, dL_dexposure=None, active=None):
-        """dL_dtau [K,6] (BatchContext's g["tau_all"]), dL_dexposure [K,2] or None, active: [K] bool / uint8 or None."""
+    def step(self, dL_dtau, dL_dexposure=None, active=None, skip=None, skip_stride=0):
+        """dL_dtau [K,6] (BatchContext's g["tau_all"]), dL_dexposure [K,2] or None, active: [K] bool / uint8 or None.
+        skip / skip_stride: BatchContext.abort_flags() -- views aborted on the device keep their pose and Adam state."""
         for t, shape in ((dL_dtau, (self.K, 6)), (dL_dexposure, (self.K, 2))):
             if t is not None and (t.device.type != "cuda" or t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != shape):
                 raise _lib.GsajError("gradients must be contiguous float32 device tensors of shape [K,6] / [K,2]")
@@ -94,7 +97,7 @@ class PoseTrackerBatch:
         _lib.check(self.lib.gsaj_pose_adam_step_batch(self.K, dL_dtau.data_ptr(), None if dL_dexposure is None else dL_dexposure.data_ptr(),
                                                       None if act is None else act.data_ptr(), self.lr[0], self.lr[1], self.lr[2],
                                                       self.lr[3], self.betas[0], self.betas[1], self.eps, self.thr,
-                                                      self.projection.data_ptr(), self.state.data_ptr(),
+                                                      self.projection.data_ptr(), self.state.data_ptr(), skip, int(skip_stride),
                                                       torch.cuda.current_stream(self.dev).cuda_stream), "gsaj_pose_adam_step_batch")
 
     def matrices(self):

@@ -300,6 +300,16 @@ class FrameContext:
                                                _stream(self.dev)), "gsaj_set_tile_band")
         self.band = (int(tile_row_begin), int(tile_row_end))
 
+    def abort_flag_ptr(self):
+        """Device address of this context's abort word (gsaj_forward_abort_flag): non-zero after an asynchronous forward that did
+        not fit the arena.  For PoseTracker.step(skip=...)."""
+        return self.lib.gsaj_forward_abort_flag(self.W, self.H, self.img.data_ptr())
+
+    def abort_flag_tensor(self):
+        """The same word as a one-element int32 view of the image workspace (for folding it into a collective)."""
+        off = self.abort_flag_ptr() - self.img.data_ptr()
+        return self.img[off:off + 4].view(torch.int32)
+
     def _ensure_binning(self, R):
         need = self.lib.gsaj_binning_workspace_bytes(R)
         if self.binning.numel() < need:
@@ -472,6 +482,10 @@ class BatchContext:
             out.append((R.value, mt.value, rc == -3))
         return out
 
+    def abort_flags(self):
+        """(address of view 0's abort word, byte stride between the views' words) for PoseTrackerBatch.step(skip=..., skip_stride=...)."""
+        return self.lib.gsaj_forward_abort_flag(self.W, self.H, self.img.data_ptr()), self.img_stride
+
     def clear_aborts(self):
         """Blocking: read and clear every view's count of aborted asynchronous forwards; returns their sum."""
         total, st = 0, _stream(self.dev)
@@ -567,6 +581,14 @@ class BatchContext:
         for i, (v0, kv, st) in enumerate(self.groups):
             call(v0, kv, cur, 4 | (1 if i > 0 else 0))
         return g
+
+    def view_sums(self, v):
+        """[P,12]: the reverse compositor's 10 sums per Gaussian of view v of the last backward (gsaj_debug_export_view_sums):
+        dL/dmean2D x, y | dL/dconic a, b, c | dL/dopacity | dL/dcolor r, g, b | dL/ddepth | 2 pads.  For parity tests."""
+        out = torch.zeros((self.P, 12), device=self.dev, dtype=_F32)
+        _lib.check(self.lib.gsaj_debug_export_view_sums(self.P, self.geom.data_ptr() + int(v) * self.geom_stride, out.data_ptr(),
+                                                        _stream(self.dev)), "gsaj_debug_export_view_sums")
+        return out
 
     def interactions(self):
         """sum over views and pixels of n_contrib (Gaussian-pixel interactions of the last forward)."""

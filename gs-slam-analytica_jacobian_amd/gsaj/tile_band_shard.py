@@ -7,7 +7,7 @@ band of tile rows (gsaj_set_tile_band: the tile rectangles of cuda_rasterizer/au
 the band's share of dL/dtau, and the shares add up to the whole-frame value.  Per iteration and rank:
 
     forward(band) -> loss seeds -> backward(pose_only)          no collective inside the data path
-    all-reduce(sum) of 11 floats: dL/dtau (6), loss, L_rgb, L_depth, dL/da, dL/db     RCCL ("nccl") / gloo in CPU tests
+    all-reduce(sum) of 12 floats: dL/dtau (6), loss, L_rgb, L_depth, dL/da, dL/db, aborted     RCCL ("nccl") / gloo in CPU tests
     pose Adam step + update_pose on every rank                   same input, same arithmetic -> the replicas stay identical
 
 The tracking loss needs no masking for this: its colour term is weighted by the rendered opacity and its depth term is
@@ -20,8 +20,11 @@ import torch
 import torch.distributed as dist
 
 TILE = 16
-REDUCED_FLOATS = 11  # dL/dtau (6) | loss, L_rgb, L_depth, dL/da, dL/db (= the out_scalars[5] of gsaj_loss_seeds, in its order)
-TAU, LOSS_TERMS, EXPOSURE_GRADS = slice(0, 6), slice(6, 9), slice(9, 11)
+# dL/dtau (6) | loss, L_rgb, L_depth, dL/da, dL/db (= the out_scalars[5] of gsaj_loss_seeds, in its order) | aborted: > 0 if a rank's
+# share of this iteration was aborted on the device (its terms are stale): summed like the rest, so EVERY rank sees it in the same
+# iteration and skips the pose step (gsaj_pose_adam_step's `skip` word)
+REDUCED_FLOATS = 12
+TAU, LOSS_TERMS, EXPOSURE_GRADS, ABORTED = slice(0, 6), slice(6, 9), slice(9, 11), slice(11, 12)
 
 
 def tile_rows(H):
@@ -84,7 +87,7 @@ def row_work(n_contrib, H=None):
 
 
 def pack_pose_terms(dL_dtau_sum, loss_scalars=None, out=None):
-    """-> the [11] tensor one all-reduce ships: dL/dtau | loss, L_rgb, L_depth, dL/da, dL/db.
+    """-> the [12] tensor one all-reduce ships: dL/dtau | loss, L_rgb, L_depth, dL/da, dL/db | aborted (left 0 here).
     loss_scalars: out_scalars[5] of gsaj_loss_seeds = {loss, L_rgb, L_depth, dL/da, dL/db} (None: zeros).  The layout is the two
     kernels' own output layouts back to back, so a caller can also hand them views of ONE buffer and skip this copy
     (gsaj.tracking.DeviceTracker does)."""
@@ -92,6 +95,7 @@ def pack_pose_terms(dL_dtau_sum, loss_scalars=None, out=None):
     out[0:6] = dL_dtau_sum
     if loss_scalars is not None:
         out[6:11] = loss_scalars[0:5]
+        out[11:].zero_()
     else:
         out[6:].zero_()
     return out

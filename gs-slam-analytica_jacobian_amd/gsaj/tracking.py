@@ -14,7 +14,12 @@ launches for a 160x120 / 3000-Gaussian frame and 0.94x at 640x480 / 50 000 -- th
 because it proves the property that matters: an iteration is a pure stream program (the replayed loop gives the eager loop's bits).
 
 With a process group (tile-band sharding, gsaj.tile_band_shard) the collective sits between the backward and the pose step:
-[forward(band) .. backward] -> all_reduce(11 floats) -> [pose step]; two graphs when captured.
+[forward(band) .. backward] -> all_reduce(12 floats) -> [pose step]; two graphs when captured.
+
+An asynchronous frame that does not fit its arena is aborted on the device: its kernels return at once and dL/dtau, the loss terms
+stay the PREVIOUS iteration's.  The pose step is handed the frame's abort word (gsaj_pose_adam_step `skip`) and then changes
+nothing -- no Adam moment, no pose; sharded, the word travels as the 12th float of the all-reduce, so every rank skips the same
+iterations and iterate() raises on every rank together.
 """
 import torch
 
@@ -51,6 +56,8 @@ class DeviceTracker:
         self.packed = torch.zeros(tbs.REDUCED_FLOATS, dtype=torch.float32, device=self.dev)
         self.ctx.g["tau_sum"] = self.packed[tbs.TAU]
         self.loss.scalars = self.packed[6:11]
+        self._abort_word = self.ctx.abort_flag_tensor()   # int32 [1], inside the image workspace
+        self._abort_ptr = self.ctx.abort_flag_ptr()
         self.gt_color = self.gt_depth = self.grad_mask = None
         self._graphs = None
         self.iterations = 0
@@ -65,9 +72,12 @@ class DeviceTracker:
         g = c.backward(self.bg, self.means, p.viewmatrix, p.projmatrix, self.praw, p.campos, self.tanfov[0], self.tanfov[1],
                        L["dL_dcolor"], L["dL_ddepth"], pose_only=True, **self.kw)
         assert g["tau_sum"].data_ptr() == self.packed.data_ptr()
+        if self._sharded():  # the abort word joins the sum: any rank's abort reaches every rank
+            self.packed[tbs.ABORTED].copy_(self._abort_word)
 
     def _step(self):
-        self.pose.step(self.packed[tbs.TAU], self.packed[tbs.EXPOSURE_GRADS])
+        skip = self.packed[tbs.ABORTED].data_ptr() if self._sharded() else self._abort_ptr
+        self.pose.step(self.packed[tbs.TAU], self.packed[tbs.EXPOSURE_GRADS], skip=skip)
 
     def set_frame(self, gt_color, gt_depth=None, grad_mask=None, w2c=None):
         """New frame: ground truth (device, [3,H,W] / [H,W]; grad_mask [1,H,W] or None) and optionally a new initial pose.
@@ -134,13 +144,23 @@ class DeviceTracker:
                 if check_every and done % check_every == 0 and bool(self.pose.converged.item() != 0.0):
                     break
         self.iterations += done
+        err = None
         try:
             self.ctx.status()
-        except _lib.GsajError:
-            # an asynchronous frame did not fit the arena / LDS sort sized earlier (the view moved onto more Gaussians): those
-            # iterations rendered nothing.  Re-size with one synchronous iteration; the caller sees the error and decides.
+        except _lib.GsajError as e:
+            err = e
+        if self._sharded():  # a rank whose own share fitted must raise with the others (they all skipped the same pose steps)
+            import torch.distributed as dist
+            flag = torch.tensor([1.0 if err else 0.0], device=self.dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+            if err is None and float(flag.item()) > 0.0:
+                err = _lib.GsajError("an asynchronous forward of another rank's tile band was aborted on the device (binning arena too small)")
+        if err is not None:
+            # an asynchronous frame did not fit the arena sized earlier (the view moved onto more Gaussians): those iterations
+            # rendered nothing and moved nothing (the pose step skips an aborted frame).  The next call re-sizes with one
+            # synchronous iteration; the caller sees the error and decides.
             self.ctx.capacity = 0
-            raise
+            raise err
         return done
 
     @property

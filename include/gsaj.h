@@ -133,6 +133,12 @@ int gsaj_rasterize_forward_async(int P, int D, int M, const float *bg, int W, in
  * from when the caller zero-filled the image workspace, which it does once, when it allocates it). */
 int gsaj_forward_aborted_count(int W, int H, void *image_ws, void *stream, int *count /*host*/);
 
+/* Device address of the frame's abort word inside the image workspace: non-zero after an asynchronous forward that did not fit
+ * its arena (every later kernel of that frame returned at once: images, dL/dtau and per-Gaussian outputs are the previous
+ * frame's); cleared by the next forward.  Stream-ordered consumers on the device read it without a host round trip:
+ * gsaj_pose_adam_step(skip = this) leaves the pose alone after an aborted frame.  NULL on invalid arguments. */
+const uint32_t *gsaj_forward_abort_flag(int W, int H, void *image_ws);
+
 /* Tile-band sharding of ONE frame (tracking on several GPUs; no counterpart in the reference, whose rasteriser is
  * single-device: cuda_rasterizer/rasterizer_impl.cu:224-352 binds every tile of the frame).  Every later forward that uses
  * this image workspace renders only tile rows [tile_row_begin, tile_row_end) of the (H + 15) / 16 rows: a Gaussian's tile
@@ -234,6 +240,11 @@ int gsaj_debug_export(int P, int R, int W, int H, const void *geom_ws, const voi
                       uint32_t *tiles_touched, uint32_t *point_list, uint32_t *ranges, float *final_T,
                       uint32_t *n_contrib, void *stream);
 
+/* After gsaj_rasterize_backward_batch: the reverse compositor's 10 sums per Gaussian of ONE view of the window (that view's block
+ * of the geometry workspace), sums [P,12] = (dL/dmean2D x, y | dL/dconic a, b, c | dL/dopacity | dL/dcolor r, g, b | dL/ddepth | 2
+ * pads) -- the per-view quantities the batched backward does not return (it returns their sums over the views), for parity tests. */
+int gsaj_debug_export_view_sums(int P, const void *geom_ws, float *sums /*dev [P,12]*/, void *stream);
+
 /* ---- per-kernel timing (bench.py's roofline leg) ----------------------------------------
  * Between gsaj_profile_begin and gsaj_profile_end every kernel launch of the library is
  * bracketed by HIP events on the stream it is launched on.  gsaj_profile_end synchronises,
@@ -307,20 +318,28 @@ int gsaj_densification_stats(int K, int P, const float *dL_dmean2D, const int *r
  *   [32]    step count    [33:35) exposure a, b (updated in place)
  *   [35:51) out world_view_transform = W2C^T     [51:67) out full_proj_transform    [67:70) out camera_center
  *   [70:76) out tau = [rho, theta] applied       [76] out |tau|     [77] out converged (1.0 / 0.0: |tau| < threshold)
- * Initialise [0:16) with the pose and zero the rest. */
+ * Initialise [0:16) with the pose and zero the rest.
+ * skip (device, may be NULL): if the 32-bit word it points to is non-zero the call changes NOTHING (no Adam moment, no step
+ * count, no pose): pass gsaj_forward_abort_flag() of the frame the gradients come from -- an aborted asynchronous frame leaves
+ * the previous iteration's dL/dtau in place -- or, with the frame sharded over ranks, a word of the all-reduced buffer that is
+ * non-zero when ANY rank's share was aborted (any non-zero bit pattern counts, e.g. a positive float). */
 #define GSAJ_POSE_STATE_FLOATS 80
 int gsaj_pose_state_floats(void);
 int gsaj_pose_adam_step(const float *dL_dtau, const float *dL_dexposure, float lr_rot, float lr_trans, float lr_exp_a,
                         float lr_exp_b, float beta1, float beta2, float eps, float converged_threshold,
-                        const float *projection_matrix, float *pose_state, void *stream);
+                        const float *projection_matrix, float *pose_state, const uint32_t *skip, void *stream);
 
 /* The same step for K poses in one launch (the keyframe poses of a mapping window, each with its own Adam state:
  * utils/slam_backend.py:255-262 steps the keyframe optimiser and calls update_pose per keyframe, skipping uid 0):
  * dL_dtau [K,6] (the dL_dtau_sum rows of gsaj_rasterize_backward_batch), dL_dexposure [K,2] or NULL, active [K] bytes or NULL
- * (0: the pose and its Adam state are left untouched), pose_states [K, GSAJ_POSE_STATE_FLOATS]; the learning rates are shared. */
+ * (0: the pose and its Adam state are left untouched), pose_states [K, GSAJ_POSE_STATE_FLOATS]; the learning rates are shared.
+ * skip (may be NULL) / skip_stride_bytes: pose k is left untouched if the word at skip + k * skip_stride_bytes is non-zero -- with
+ * skip = gsaj_forward_abort_flag(view 0's image workspace) and skip_stride_bytes = gsaj_image_workspace_bytes(W, H), the views of a
+ * batched window that were aborted on the device. */
 int gsaj_pose_adam_step_batch(int K, const float *dL_dtau, const float *dL_dexposure, const uint8_t *active, float lr_rot,
                               float lr_trans, float lr_exp_a, float lr_exp_b, float beta1, float beta2, float eps,
-                              float converged_threshold, const float *projection_matrix, float *pose_states, void *stream);
+                              float converged_threshold, const float *projection_matrix, float *pose_states, const uint32_t *skip,
+                              size_t skip_stride_bytes, void *stream);
 
 /* ---- distCUDA2 -------------------------------------------------------------------
  * simple_knn._C.distCUDA2 (reference submodules/simple-knn/simple_knn.cu:45-220, spatial.cu): for P points

@@ -374,3 +374,76 @@ def assert_counts_close(got, want, st, tag=None, flip_fraction=2e-4):
     assert ys.size <= max(1.0, flip_fraction * got.size), (tag, ys.size)
     for py, px in zip(ys, xs):
         assert borderline_pixel(st, int(px), int(py)), (tag, "n_contrib of pixel (%d,%d): %d vs %d, no borderline contributor" % (px, py, got[py, px], want[py, px]))
+
+
+def assert_touched_close(got, want, st, tag=None, rel=BORDER_REL, rel_T=BORDER_REL_T, max_gaussians=2000):
+    """n_touched [P] (forward.cu:512-514: pixels where the Gaussian contributes while T(1 - alpha) > 0.5) is integer output, but a
+    count of fp32 decisions: it may differ from the oracle's only by pixels whose decision for THAT (pixel, entry) sits on a
+    threshold to within the rounding of any fp32 evaluation -- T(1 - alpha) within its accumulated relative uncertainty of 0.5,
+    or a cut-off borderline contributor earlier in the pixel's walk (the same criteria as borderline_pixel).  For every Gaussian
+    whose count differs, the pixels of its tiles are walked up to its entry and the uncertain ones counted: the difference must
+    not exceed them."""
+    got = np.asarray(got).astype(np.int64).reshape(-1)
+    want = np.asarray(want).astype(np.int64).reshape(-1)
+    ids = np.nonzero(got != want)[0]
+    _errlog((tag or "n_touched"), n_diff=int(ids.size), sum_abs=int(np.abs(got - want).sum()))
+    assert ids.size <= max_gaussians, (tag, "n_touched differs for %d Gaussians" % ids.size)
+    if ids.size == 0:
+        return 0
+    W, H = st["W"], st["H"]
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    f, eps, thr = np.float32, 2.0 ** -23, 1.0 / 255.0
+    pl, ranges, m2, co = st["point_list"], st["ranges"], st["means2D"], st["conic_opacity"]
+    for gid in ids:
+        r = int(st["radii"][gid])
+        mx, my = m2[gid]
+        # (the Gaussian's tile rectangle, one tile wider on every side: tiles whose list does not hold it are skipped below)
+        x0, x1 = min(gx, max(0, int((mx - r) / 16) - 1)), min(gx, max(0, int((mx + r + 15) / 16) + 1))
+        y0, y1 = min(gy, max(0, int((my - r) / 16) - 1)), min(gy, max(0, int((my + r + 15) / 16) + 1))
+        uncertain = 0
+        for ty in range(y0, y1):
+            for tx in range(x0, x1):
+                beg, end = ranges[ty * gx + tx]
+                lst = pl[beg:end].astype(np.int64)
+                pos = np.nonzero(lst == gid)[0]
+                if pos.size == 0:
+                    continue
+                ent = lst[: int(pos[0]) + 1]
+                px = (tx * 16 + np.arange(16))[None, :].repeat(16, 0).reshape(-1)
+                py = (ty * 16 + np.arange(16))[:, None].repeat(16, 1).reshape(-1)
+                ok_px = (px < W) & (py < H)
+                dx = m2[ent, 0][None, :] - px[:, None].astype(f)
+                dy = m2[ent, 1][None, :] - py[:, None].astype(f)
+                a_, b_, c_, o_ = (co[ent, k][None, :] for k in range(4))
+                power = (f(-0.5) * (a_ * dx * dx + c_ * dy * dy) - b_ * dx * dy).astype(np.float64)
+                mag = (0.5 * (np.abs(a_) * dx * dx + np.abs(c_) * dy * dy) + np.abs(b_ * dx * dy)).astype(np.float64)
+                alpha = np.minimum(0.99, o_.astype(np.float64) * np.exp(np.minimum(power, 0.0)))
+                a_rel = rel + 4.0 * eps * mag
+                contrib = (power <= 0) & (alpha >= thr)
+                one_m = np.where(contrib, 1.0 - alpha, 1.0)
+                T_after = np.cumprod(one_m, axis=1)          # T(1 - alpha) of entry k where it contributes
+                stop = contrib & (T_after < 1e-4)             # the walk ends BEFORE the first such entry
+                alive = np.cumsum(stop, axis=1) == 0          # entries the walk still reaches (and that one included: it is tested)
+                reached = np.concatenate([np.ones((alive.shape[0], 1), bool), alive[:, :-1]], axis=1)
+                t_rel = rel_T + np.cumsum(np.where(contrib, a_rel * alpha / np.maximum(1.0 - alpha, 1e-6), 0.0), axis=1)
+                near_alpha = reached & (np.abs(alpha - thr) <= a_rel * thr)
+                near_pow = reached & (np.abs(power) <= 4.0 * eps * mag + 1e-7)
+                near_stop = reached & contrib & (np.abs(T_after - 1e-4) <= t_rel * 1e-4)
+                border = (near_alpha | near_pow | near_stop).any(axis=1)
+                k = ent.shape[0] - 1
+                near_half = reached[:, k] & (np.abs(T_after[:, k] - 0.5) <= 0.5 * t_rel[:, k]) & (alpha[:, k] >= thr * (1.0 - a_rel[:, k]))
+                uncertain += int(((border | near_half) & ok_px).sum())
+        assert abs(int(got[gid] - want[gid])) <= uncertain, (tag, "n_touched of Gaussian %d: %d vs %d, but only %d of its pixels have a "
+                                                             "decision within rounding of a threshold" % (gid, got[gid], want[gid], uncertain))
+    return int(ids.size)
+
+
+def view_grads_from_sums(sums12, tau_rows, tau_sum):
+    """The per-view outputs of the batched backward in GRAD_NAMES order (None where the batched path has no per-view output):
+    sums12 [P,12] = BatchContext.view_sums(v) (the reverse compositor's 10 sums per Gaussian: mean2D x y | conic a b c | opacity |
+    colour r g b | depth | 2 pads), tau_rows [P,6], tau_sum [6]."""
+    s = np.asarray(sums12, np.float32)
+    P = s.shape[0]
+    m2 = np.concatenate([s[:, 0:2], np.zeros((P, 1), np.float32)], axis=1)
+    conic = np.stack([s[:, 2], s[:, 3], np.zeros(P, np.float32), s[:, 4]], axis=1).reshape(P, 2, 2)
+    return (m2, s[:, 6:9].copy(), s[:, 5:6].copy(), None, None, None, None, None, np.asarray(tau_rows), np.asarray(tau_sum), conic, s[:, 9:10].copy())

@@ -87,6 +87,13 @@ def test_load_tensors_reads_torchscript_archives_without_running_them(tmp_path):
     assert GaussianModel(3).load_tensors(str(tmp_path / "nope.pt"), device="cpu") is False
     torch.save([ps[0]], str(tmp_path / "short.pt"))
     assert GaussianModel(3).load_tensors(str(tmp_path / "short.pt"), device="cpu") is False
+    # an archive whose tensors are not exactly the six parameters (a buffer in between, or a seventh tensor) would be mapped to the
+    # wrong fields position by position: it is refused instead (the restricted reader cannot tell buffers from parameters)
+    full = [p.detach() for p in m.parameters()]
+    torch.save(full + [torch.zeros(3)], str(tmp_path / "seven.pt"))
+    assert GaussianModel(3).load_tensors(str(tmp_path / "seven.pt"), device="cpu") is False
+    torch.save([full[0], torch.zeros(41, 7), *full[1:5]], str(tmp_path / "shifted.pt"))  # six tensors, one of them a stranger
+    assert GaussianModel(3).load_tensors(str(tmp_path / "shifted.pt"), device="cpu") is False
 
 
 def test_parameter_reader_refuses_foreign_callables(tmp_path):

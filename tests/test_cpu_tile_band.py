@@ -57,8 +57,9 @@ def test_pack_pose_terms_layout():
     tau = torch.arange(6, dtype=torch.float32)
     scalars = torch.tensor([10.0, 11.0, 12.0, 13.0, 14.0])  # loss, L_rgb, L_depth, dL/da, dL/db
     p = tbs.pack_pose_terms(tau, scalars)
-    assert p.tolist() == [0, 1, 2, 3, 4, 5, 10, 11, 12, 13, 14]
-    assert tbs.pack_pose_terms(tau).tolist() == [0, 1, 2, 3, 4, 5, 0, 0, 0, 0, 0]
+    assert p.tolist() == [0, 1, 2, 3, 4, 5, 10, 11, 12, 13, 14, 0]   # (the 12th float: "a rank's share was aborted", set by the tracker)
+    assert tbs.pack_pose_terms(tau).tolist() == [0, 1, 2, 3, 4, 5, 0, 0, 0, 0, 0, 0]
+    assert tbs.REDUCED_FLOATS == 12 and p[tbs.ABORTED].tolist() == [0.0]
     assert tbs.allreduce_pose_terms(p) is p  # no process group: identity
 
 

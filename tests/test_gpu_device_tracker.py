@@ -138,7 +138,11 @@ def test_arena_overflow_is_reported_and_the_next_call_recovers():
     tr.ctx.capacity = 64  # pretend the arena was sized for a nearly empty view ...
     tr._graphs = None     # ... before the graph was captured (launch arguments are frozen into a captured graph)
     with pytest.raises(_lib.GsajError, match="aborted"):
-        tr.iterate(2)
+        tr.iterate(3)
+    # the aborted iterations rendered nothing, so their dL/dtau was the last good iteration's: the pose step must have skipped
+    # them (gsaj_pose_adam_step's `skip` word = the frame's abort flag) -- pose, Adam moments and step count untouched
+    assert torch.equal(tr.w2c, good)
+    assert float(tr.pose.state[32]) == 2.0
     tr.set_frame(gt_c, gt_d, w2c=w2c0)
     assert tr.iterate(2) == 2  # re-sized by a synchronous first iteration, graph re-captured if the arena moved
     assert torch.equal(tr.w2c, good)

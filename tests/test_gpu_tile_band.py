@@ -210,6 +210,49 @@ def test_band_on_a_batched_window_equals_banded_single_views():
     assert float(bc.opacity[1][:, : band[0] * 16].abs().max()) > 0.0 and float(bc.opacity[0][:, : band[0] * 16].abs().max()) == 0.0
 
 
+def test_band_survives_the_arena_resize_of_a_batched_window():
+    """BatchContext.forward(sync=True) re-runs the batch after growing an arena that was too small.  The re-size must not lose the
+    views' tile bands (they live in the image workspaces: zeroing those made every view render the whole frame, and a sum
+    all-reduce over band-sharded ranks then counted gradients twice): with a tiny initial capacity, the band shares of a window
+    still add up to the whole-frame gradients."""
+    import torch
+    from gsaj.rasterizer import BatchContext
+
+    cam0, sc, deg = hp.make("p6000_640x480_sh1")
+    K = 2
+    cams = syn.keyframe_cameras(K, W=cam0["W"], H=cam0["H"], fx=cam0["fx"], fy=cam0["fy"], cx=cam0["cx"], cy=cam0["cy"])
+    dev, t, M, kw, a = _tensors(cam0, sc)
+    P, W, H = sc["means3D"].shape[0], cam0["W"], cam0["H"]
+    views, projs, cps = (t(np.stack([c[k] for c in cams])) for k in ("viewmatrix", "projmatrix", "campos"))
+    seeds = [hp.seeds(cam0, seed=90 + k) for k in range(K)]
+    dLc, dLd = t(np.stack([s[0] for s in seeds])), t(np.stack([s[1] for s in seeds]))
+
+    def window(band, capacity):
+        bc = BatchContext(K, P, W, H, M, dev)
+        if band is not None:
+            bc.set_tile_band(*band)
+        if capacity:
+            bc._size(capacity)  # far too small: every view aborts, forward(sync=True) must grow the arena and re-run
+        st = bc.forward(a["bg"], a["means"], a["opac"], views, projs, cps, cam0["tanfovx"], cam0["tanfovy"], sh_degree=deg, **kw)
+        assert not any(ab for _, _, ab in st)
+        g = bc.backward(a["bg"], a["means"], views, projs, a["praw"], cps, cam0["tanfovx"], cam0["tanfovy"], dLc, dLd, sh_degree=deg, **kw)
+        return bc, {n: g[n].clone() for n in ("mean3D", "opacity", "sh", "scale", "rot", "tau_all")}, st
+
+    whole, gw, stw = window(None, 0)
+    rows = tbs.tile_rows(H)
+    bands = [(0, 11), (11, rows)]
+    shares = [window(b, 300) for b in bands]
+    for (bc, g, st), (b0, b1) in zip(shares, bands):
+        assert bc.capacity > 300  # the re-size happened
+        for k in range(K):  # ... and the band is still in force: nothing outside it
+            assert float(bc.opacity[k][:, : b0 * 16].abs().max()) == 0.0 and float(bc.opacity[k][:, b1 * 16:].abs().max()) == 0.0
+    assert [sum(s[2][k][0] for s in shares) for k in range(K)] == [stw[k][0] for k in range(K)]  # instance counts add up
+    for n in gw:
+        tot = sum(s[1][n].double() for s in shares)
+        e = float((tot - gw[n].double()).abs().max() / gw[n].double().abs().max())
+        assert e < 5e-6, (n, e)
+
+
 def test_uninitialised_image_workspace_is_not_mistaken_for_a_band():
     """The synchronous entry points do not ask for a zeroed image workspace (the drop-in binding hands over torch.empty
     memory): whatever bytes it holds, the whole frame is rendered."""
