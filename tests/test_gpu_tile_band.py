@@ -245,7 +245,8 @@ def test_band_survives_the_arena_resize_of_a_batched_window():
     for (bc, g, st), (b0, b1) in zip(shares, bands):
         assert bc.capacity > 300  # the re-size happened
         for k in range(K):  # ... and the band is still in force: nothing outside it
-            assert float(bc.opacity[k][:, : b0 * 16].abs().max()) == 0.0 and float(bc.opacity[k][:, b1 * 16:].abs().max()) == 0.0
+            outside = torch.cat([bc.opacity[k][:, : b0 * 16].reshape(-1), bc.opacity[k][:, b1 * 16:].reshape(-1)])
+            assert outside.numel() > 0 and float(outside.abs().max()) == 0.0
     assert [sum(s[2][k][0] for s in shares) for k in range(K)] == [stw[k][0] for k in range(K)]  # instance counts add up
     for n in gw:
         tot = sum(s[1][n].double() for s in shares)
