@@ -721,14 +721,21 @@ __global__ __launch_bounds__(256) void k_chain_view(BwdParams p, GeomWS g0, Imag
   for (int k = 0; k < MC; k++) w[k] = 0.f;
   float3 gmask = make_float3(0.f, 0.f, 0.f);
   if (vis) {
-    gaussian_chain_geom(p, mean, c6, s0, s1, s2, o, tau);
+    // the view-direction term first: its 3 M coefficient loads are consumed (and their registers free) before the geometric
+    // chain's own peak
+    float3 dmean = make_float3(0.f, 0.f, 0.f);
     if (SHW > 0) {
       const float *cam = p.campos + 3 * v;
       constexpr int DEG_MAX = MC >= 16 ? 3 : (MC >= 9 ? 2 : (MC >= 4 ? 1 : 0));  // (the storage bounds the degree: dead bands compile away)
-      const float3 dmean = sh_backward<1>(min(p.D, DEG_MAX), p.M, mean, make_float3(cam[0], cam[1], cam[2]), p.shs + ii * SHW, w, cl, o.col);
+      const float3 gcol = make_float3(s1.z, s1.w, s2.x);
+      dmean = sh_backward<1>(min(p.D, DEG_MAX), p.M, mean, make_float3(cam[0], cam[1], cam[2]), p.shs + ii * SHW, w, cl, gcol);
+      gmask = make_float3(cl[0] ? 0.f : gcol.x, cl[1] ? 0.f : gcol.y, cl[2] ? 0.f : gcol.z);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    gaussian_chain_geom(p, mean, c6, s0, s1, s2, o, tau);
+    if (SHW > 0) {
       o.gm.x += dmean.x; o.gm.y += dmean.y; o.gm.z += dmean.z;
       tau[0] -= dmean.x; tau[1] -= dmean.y; tau[2] -= dmean.z;
-      gmask = make_float3(cl[0] ? 0.f : o.col.x, cl[1] ? 0.f : o.col.y, cl[2] ? 0.f : o.col.z);
     }
   }
   // ---- this view's dL/dtau: wave partials (the single-view kernel's butterfly), one slot per 64 Gaussians, added up in slot order

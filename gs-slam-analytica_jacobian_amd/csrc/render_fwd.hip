@@ -146,22 +146,25 @@ __global__ __launch_bounds__(GSAJ_FWD_THREADS) __attribute__((amdgpu_waves_per_e
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      int cnt = 0;  // lane l: #pixels of this wave that count packed entry l as "touched"
+      // lane l: #pixels of this wave that count packed entry l as "touched".  The four counts of a step (each <= 64) travel as
+      // the bytes of ONE scalar word to the four lanes of the step (one compare + select per FOUR entries instead of per entry);
+      // every lane takes its byte after the loop
+      uint32_t cnt4 = 0u;
       bool wave_done = false;
       // two entries per step; the records of the next step are requested from LDS before this step's arithmetic
       float4 a0 = rec[0], a1 = rec[1], a2 = rec[2], b0 = rec[3], b1 = rec[4], b2 = rec[5];
       for (int i = 0; i < nrel; i += 4) {
         const float4 c0 = rec[i * REC_F4 + 6], c1 = rec[i * REC_F4 + 7], c2 = rec[i * REC_F4 + 8];
         const float4 d0 = rec[i * REC_F4 + 9], d1 = rec[i * REC_F4 + 10], d2 = rec[i * REC_F4 + 11];
+        uint32_t pack = 0u;  // (scalar)
         {
           float tA, tB;
           const bool okA = composite(a0, a1, a2, tA);
           const bool okB = composite(b0, b1, b2, tB);
           if (counting) {
-            const int nA = __popcll(__builtin_amdgcn_ballot_w64(okA && tA > 0.5f));
-            const int nB = __popcll(__builtin_amdgcn_ballot_w64(okB && tB > 0.5f));
-            cnt = (lane == i) ? nA : cnt;
-            cnt = (lane == i + 1) ? nB : cnt;
+            const uint32_t nA = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(okA && tA > 0.5f));
+            const uint32_t nB = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(okB && tB > 0.5f));
+            pack = nA | (nB << 8);
             counting = __builtin_amdgcn_ballot_w64(T > 0.5f) != 0ull;
           }
         }
@@ -172,18 +175,19 @@ __global__ __launch_bounds__(GSAJ_FWD_THREADS) __attribute__((amdgpu_waves_per_e
           const bool okC = composite(c0, c1, c2, tC);
           const bool okD = composite(d0, d1, d2, tD);
           if (counting) {
-            const int nC = __popcll(__builtin_amdgcn_ballot_w64(okC && tC > 0.5f));
-            const int nD = __popcll(__builtin_amdgcn_ballot_w64(okD && tD > 0.5f));
-            cnt = (lane == i + 2) ? nC : cnt;
-            cnt = (lane == i + 3) ? nD : cnt;
+            const uint32_t nC = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(okC && tC > 0.5f));
+            const uint32_t nD = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(okD && tD > 0.5f));
+            pack |= (nC << 16) | (nD << 24);
             counting = __builtin_amdgcn_ballot_w64(T > 0.5f) != 0ull;
           }
         }
+        cnt4 = ((lane >> 2) == (i >> 2)) ? pack : cnt4;
         if (__builtin_amdgcn_ballot_w64(!done) == 0ull) {
           wave_done = true;
           break;
         }
       }
+      const int cnt = (int)((cnt4 >> (8 * (lane & 3))) & 0xffu);
       if (lane < nrel && cnt > 0) {
         const uint32_t id = __float_as_uint(rec[lane * REC_F4 + 0].w);
         atomicAdd(&n_touched[id], cnt);
