@@ -7,6 +7,7 @@
 #include <mutex>
 
 #include "gsaj_common.h"
+#include "loss_terms.h"
 
 static thread_local char g_err[512] = "";
 
@@ -286,13 +287,14 @@ int gsaj_rasterize_forward(int P, int D, int M, const float *bg, int W, int H, c
   return rc == GSAJ_OK ? R : rc;
 }
 
-int gsaj_rasterize_forward_async(int P, int D, int M, const float *bg, int W, int H, const float *means3D, const float *shs,
-                                 const float *colors_precomp, const float *opacities, const float *scales,
-                                 float scale_modifier, const float *rotations, const float *cov3D_precomp,
-                                 const float *viewmatrix, const float *projmatrix, const float *campos, float tanfovx,
-                                 float tanfovy, int prefiltered, float *out_color, float *out_depth, float *out_opacity,
-                                 int *radii, int *n_touched, void *geom_ws, void *binning_ws, size_t binning_ws_bytes,
-                                 int capacity, int tile_list_capacity, void *image_ws, int flags, void *stream) {
+static int forward_async_impl(int P, int D, int M, const float *bg, int W, int H, const float *means3D, const float *shs,
+                              const float *colors_precomp, const float *opacities, const float *scales,
+                              float scale_modifier, const float *rotations, const float *cov3D_precomp,
+                              const float *viewmatrix, const float *projmatrix, const float *campos, float tanfovx,
+                              float tanfovy, int prefiltered, float *out_color, float *out_depth, float *out_opacity,
+                              int *radii, int *n_touched, void *geom_ws, void *binning_ws, size_t binning_ws_bytes,
+                              int capacity, int tile_list_capacity, void *image_ws, int flags, void *stream, const FusedLoss *fl,
+                              float *out_scalars) {
   if (capacity <= 0 || !binning_ws || !bg || !out_color || !out_depth || !out_opacity || !n_touched) {
     gsaj_set_error("gsaj_rasterize_forward_async: invalid argument");
     return GSAJ_ERR_INVALID_ARGUMENT;
@@ -318,7 +320,59 @@ int gsaj_rasterize_forward_async(int P, int D, int M, const float *bg, int W, in
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
   const int sort_cap = (tile_list_capacity > 0 && tile_list_capacity < SORT_CAP) ? tile_list_capacity : SORT_CAP;
   if ((rc = launch_tile_binning(P, sort_cap, (flags & GSAJ_FWD_RECORDS_FP16) ? 1 : 0, gx, gy, g, b, im, 1, ViewStrides{0, 0, 0}, s)) != GSAJ_OK) return rc;
-  return launch_render_forward(P, W, H, gx, gy, bg, g, b, im, out_color, out_depth, out_opacity, n_touched, 1, ViewStrides{0, 0, 0}, s);
+  if ((rc = launch_render_forward(P, W, H, gx, gy, bg, g, b, im, out_color, out_depth, out_opacity, n_touched, 1, ViewStrides{0, 0, 0}, s, fl)) != GSAJ_OK) return rc;
+  if (fl) return launch_loss_finalize(*fl, gsaj_fwd_loss_slots(W, H), W, H, im.counters + 4, out_scalars, s);
+  return GSAJ_OK;
+}
+
+int gsaj_rasterize_forward_async(int P, int D, int M, const float *bg, int W, int H, const float *means3D, const float *shs,
+                                 const float *colors_precomp, const float *opacities, const float *scales,
+                                 float scale_modifier, const float *rotations, const float *cov3D_precomp,
+                                 const float *viewmatrix, const float *projmatrix, const float *campos, float tanfovx,
+                                 float tanfovy, int prefiltered, float *out_color, float *out_depth, float *out_opacity,
+                                 int *radii, int *n_touched, void *geom_ws, void *binning_ws, size_t binning_ws_bytes,
+                                 int capacity, int tile_list_capacity, void *image_ws, int flags, void *stream) {
+  return forward_async_impl(P, D, M, bg, W, H, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp,
+                            viewmatrix, projmatrix, campos, tanfovx, tanfovy, prefiltered, out_color, out_depth, out_opacity, radii,
+                            n_touched, geom_ws, binning_ws, binning_ws_bytes, capacity, tile_list_capacity, image_ws, flags, stream,
+                            nullptr, nullptr);
+}
+
+static int fused_loss_args(const char *who, int loss_flags, const float *gt_color, const float *gt_depth, const float *exposure_a,
+                           const float *exposure_b) {
+  const bool mono = loss_flags & GSAJ_LOSS_MONOCULAR, noexp = loss_flags & GSAJ_LOSS_NO_EXPOSURE;
+  if ((loss_flags & GSAJ_LOSS_COMPUTE_LOSS) || !gt_color || (!mono && !gt_depth) || (!noexp && (!exposure_a || !exposure_b))) {
+    gsaj_set_error("%s: invalid loss arguments (flags=%d; GSAJ_LOSS_COMPUTE_LOSS has no fused form)", who, loss_flags);
+    return GSAJ_ERR_INVALID_ARGUMENT;
+  }
+  return GSAJ_OK;
+}
+
+size_t gsaj_fused_loss_workspace_bytes(int W, int H) { return (size_t)gsaj_fwd_loss_slots(W, H) * 4 * sizeof(float) + 256; }
+
+int gsaj_rasterize_forward_loss(int P, int D, int M, const float *bg, int W, int H, const float *means3D, const float *shs,
+                                const float *colors_precomp, const float *opacities, const float *scales, float scale_modifier,
+                                const float *rotations, const float *cov3D_precomp, const float *viewmatrix,
+                                const float *projmatrix, const float *campos, float tanfovx, float tanfovy, int prefiltered,
+                                float *out_color, float *out_depth, float *out_opacity, int *radii, int *n_touched, void *geom_ws,
+                                void *binning_ws, size_t binning_ws_bytes, int capacity, int tile_list_capacity, void *image_ws,
+                                int flags, int loss_flags, float alpha, float rgb_boundary_threshold, const float *gt_color,
+                                const float *gt_depth, const uint8_t *grad_mask, const float *exposure_a, const float *exposure_b,
+                                float *out_scalars, void *loss_ws, void *stream) {
+  int rc = fused_loss_args("gsaj_rasterize_forward_loss", loss_flags, gt_color, gt_depth, exposure_a, exposure_b);
+  if (rc != GSAJ_OK) return rc;
+  if (!out_scalars || !loss_ws) {
+    gsaj_set_error("gsaj_rasterize_forward_loss: out_scalars and loss_ws are required");
+    return GSAJ_ERR_INVALID_ARGUMENT;
+  }
+  FusedLoss fl{};
+  fl.flags = loss_flags; fl.alpha = alpha; fl.rgb_thr = rgb_boundary_threshold;
+  fl.gt_color = gt_color; fl.gt_depth = gt_depth; fl.grad_mask = grad_mask; fl.exp_a = exposure_a; fl.exp_b = exposure_b;
+  fl.partials = reinterpret_cast<float *>(align_base(loss_ws));
+  return forward_async_impl(P, D, M, bg, W, H, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp,
+                            viewmatrix, projmatrix, campos, tanfovx, tanfovy, prefiltered, out_color, out_depth, out_opacity, radii,
+                            n_touched, geom_ws, binning_ws, binning_ws_bytes, capacity, tile_list_capacity, image_ws, flags, stream, &fl,
+                            out_scalars);
 }
 
 // ---- batched multi-view entry points: K views of ONE Gaussian map (a mapping window) --------------------------------
@@ -436,20 +490,20 @@ int gsaj_rasterize_backward_batch(int K, int P, int D, int M, int capacity, cons
   return launch_gaussian_backward_batch(p, K, g, b, im, vs, (flags & GSAJ_BWD_ACCUMULATE) ? 1 : 0, s);
 }
 
-int gsaj_rasterize_backward(int P, int D, int M, int R, const float *bg, int W, int H, const float *means3D,
-                            const float *shs, const float *colors_precomp, const float *scales, float scale_modifier,
-                            const float *rotations, const float *cov3D_precomp, const float *viewmatrix,
-                            const float *projmatrix, const float *projmatrix_raw, const float *campos, float tanfovx,
-                            float tanfovy, const int *radii, void *geom_ws, void *binning_ws, void *image_ws,
-                            const float *dL_dpix, const float *dL_dpix_depth, float *dL_dmean2D, float *dL_dconic,
-                            float *dL_dopacity, float *dL_dcolor, float *dL_ddepth, float *dL_dmean3D,
-                            float *dL_dcov3D, float *dL_dsh, float *dL_dscale, float *dL_drot, float *dL_dtau,
-                            float *dL_dtau_sum, void *stream) {
+static int backward_impl(int P, int D, int M, int R, const float *bg, int W, int H, const float *means3D,
+                         const float *shs, const float *colors_precomp, const float *scales, float scale_modifier,
+                         const float *rotations, const float *cov3D_precomp, const float *viewmatrix,
+                         const float *projmatrix, const float *projmatrix_raw, const float *campos, float tanfovx,
+                         float tanfovy, const int *radii, void *geom_ws, void *binning_ws, void *image_ws,
+                         const float *dL_dpix, const float *dL_dpix_depth, float *dL_dmean2D, float *dL_dconic,
+                         float *dL_dopacity, float *dL_dcolor, float *dL_ddepth, float *dL_dmean3D,
+                         float *dL_dcov3D, float *dL_dsh, float *dL_dscale, float *dL_drot, float *dL_dtau,
+                         float *dL_dtau_sum, void *stream, const FusedLoss *fl) {
   // pose-only mode (tracking: only the camera is optimised): every per-Gaussian output pointer NULL, dL_dtau_sum given
   const bool pose_only = !dL_dmean2D && !dL_dconic && !dL_dopacity && !dL_dcolor && !dL_ddepth && !dL_dmean3D && !dL_dcov3D &&
                          !dL_dsh && !dL_dscale && !dL_drot && dL_dtau_sum;
   if (P <= 0 || R < 0 || W <= 0 || H <= 0 || !bg || !means3D || !viewmatrix || !projmatrix || !projmatrix_raw ||
-      !geom_ws || !binning_ws || !image_ws || !dL_dpix || !dL_dpix_depth ||
+      !geom_ws || !binning_ws || !image_ws || (!fl && (!dL_dpix || !dL_dpix_depth)) ||
       (!pose_only && (!dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_ddepth || !dL_dmean3D || !dL_dcov3D))) {
     gsaj_set_error("gsaj_rasterize_backward: invalid argument");
     return GSAJ_ERR_INVALID_ARGUMENT;
@@ -468,7 +522,7 @@ int gsaj_rasterize_backward(int P, int D, int M, int R, const float *bg, int W, 
   bin_carve(align_base(binning_ws), (size_t)R, &b);
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
   // every output row is written by the kernels (zeros for culled Gaussians): no memsets
-  int rc = launch_render_backward(R, W, H, gx, gy, bg, g, b, im, dL_dpix, dL_dpix_depth, 1, ViewStrides{0, 0, 0}, s);
+  int rc = launch_render_backward(R, W, H, gx, gy, bg, g, b, im, dL_dpix, dL_dpix_depth, 1, ViewStrides{0, 0, 0}, s, fl);
   if (rc != GSAJ_OK) return rc;
   BwdParams p;
   p.P = P; p.D = D; p.M = M; p.W = W; p.H = H;
@@ -485,6 +539,47 @@ int gsaj_rasterize_backward(int P, int D, int M, int R, const float *bg, int W, 
   p.dL_dscale = dL_dscale; p.dL_drot = dL_drot; p.dL_dtau = dL_dtau; p.dL_dtau_sum = dL_dtau_sum;
   (void)colors_precomp;
   return launch_gaussian_backward(p, g, b, im, s);
+}
+
+int gsaj_rasterize_backward(int P, int D, int M, int R, const float *bg, int W, int H, const float *means3D,
+                            const float *shs, const float *colors_precomp, const float *scales, float scale_modifier,
+                            const float *rotations, const float *cov3D_precomp, const float *viewmatrix,
+                            const float *projmatrix, const float *projmatrix_raw, const float *campos, float tanfovx,
+                            float tanfovy, const int *radii, void *geom_ws, void *binning_ws, void *image_ws,
+                            const float *dL_dpix, const float *dL_dpix_depth, float *dL_dmean2D, float *dL_dconic,
+                            float *dL_dopacity, float *dL_dcolor, float *dL_ddepth, float *dL_dmean3D,
+                            float *dL_dcov3D, float *dL_dsh, float *dL_dscale, float *dL_drot, float *dL_dtau,
+                            float *dL_dtau_sum, void *stream) {
+  return backward_impl(P, D, M, R, bg, W, H, means3D, shs, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,
+                       projmatrix, projmatrix_raw, campos, tanfovx, tanfovy, radii, geom_ws, binning_ws, image_ws, dL_dpix, dL_dpix_depth,
+                       dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_ddepth, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, dL_dtau,
+                       dL_dtau_sum, stream, nullptr);
+}
+
+int gsaj_rasterize_backward_loss(int P, int D, int M, int R, const float *bg, int W, int H, const float *means3D, const float *shs,
+                                 const float *colors_precomp, const float *scales, float scale_modifier, const float *rotations,
+                                 const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix,
+                                 const float *projmatrix_raw, const float *campos, float tanfovx, float tanfovy, const int *radii,
+                                 void *geom_ws, void *binning_ws, void *image_ws, int loss_flags, float alpha,
+                                 float rgb_boundary_threshold, const float *color, const float *depth, const float *opacity,
+                                 const float *gt_color, const float *gt_depth, const uint8_t *grad_mask, const float *exposure_a,
+                                 const float *exposure_b, float *dL_dmean2D, float *dL_dconic, float *dL_dopacity, float *dL_dcolor,
+                                 float *dL_ddepth, float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh, float *dL_dscale,
+                                 float *dL_drot, float *dL_dtau, float *dL_dtau_sum, void *stream) {
+  int rc = fused_loss_args("gsaj_rasterize_backward_loss", loss_flags, gt_color, gt_depth, exposure_a, exposure_b);
+  if (rc != GSAJ_OK) return rc;
+  if (!color || !opacity || (!(loss_flags & GSAJ_LOSS_MONOCULAR) && !depth)) {
+    gsaj_set_error("gsaj_rasterize_backward_loss: the forward's color / depth / opacity images are required");
+    return GSAJ_ERR_INVALID_ARGUMENT;
+  }
+  FusedLoss fl{};
+  fl.flags = loss_flags; fl.alpha = alpha; fl.rgb_thr = rgb_boundary_threshold;
+  fl.gt_color = gt_color; fl.gt_depth = gt_depth; fl.grad_mask = grad_mask; fl.exp_a = exposure_a; fl.exp_b = exposure_b;
+  fl.color = color; fl.depth = depth; fl.opacity = opacity;
+  return backward_impl(P, D, M, R, bg, W, H, means3D, shs, colors_precomp, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,
+                       projmatrix, projmatrix_raw, campos, tanfovx, tanfovy, radii, geom_ws, binning_ws, image_ws, nullptr, nullptr,
+                       dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_ddepth, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, dL_dtau,
+                       dL_dtau_sum, stream, &fl);
 }
 
 int gsaj_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix, uint8_t *present,

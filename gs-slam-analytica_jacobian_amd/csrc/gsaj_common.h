@@ -213,13 +213,19 @@ int launch_preprocess(const FwdParams &p, int *radii, int *n_touched, const Geom
 int launch_tile_binning(int P, int sort_cap, int rec16, int grid_x, int grid_y, const GeomWS &g, const BinWS &b, const ImageWS &im,
                         int views, ViewStrides vs, hipStream_t s);
 // out_color [views,3,H,W], out_depth / out_opacity [views,1,H,W], n_touched [views,P]
+struct FusedLoss;  // loss_terms.h
+// fl != NULL (single view only): the forward's epilogue also sums the loss terms of its pixels into fl->partials
+// [gsaj_fwd_loss_slots(W, H)][4]
 int launch_render_forward(int P, int W, int H, int grid_x, int grid_y, const float *bg, const GeomWS &g, const BinWS &b,
                           const ImageWS &im, float *out_color, float *out_depth, float *out_opacity, int *n_touched, int views,
-                          ViewStrides vs, hipStream_t s);
+                          ViewStrides vs, hipStream_t s, const FusedLoss *fl = nullptr);
+int gsaj_fwd_loss_slots(int W, int H);  // workgroups of the forward compositor = loss partial slots
+int launch_loss_finalize(const FusedLoss &fl, int nslots, int W, int H, const uint32_t *aborted, float *out_scalars, hipStream_t s);
 // dL_dpix [views,3,H,W], dL_dpix_depth [views,1,H,W]
+// fl != NULL (single view only): the pixel seeds are derived from fl's images + ground truth instead of read from dL_dpix
 int launch_render_backward(int R, int W, int H, int grid_x, int grid_y, const float *bg, const GeomWS &g, const BinWS &b,
                            const ImageWS &im, const float *dL_dpix, const float *dL_dpix_depth, int views, ViewStrides vs,
-                           hipStream_t s);
+                           hipStream_t s, const FusedLoss *fl = nullptr);
 struct BwdParams {
   int P, D, M, W, H;
   const float *means3D, *shs, *scales, *rotations, *cov3Ds;

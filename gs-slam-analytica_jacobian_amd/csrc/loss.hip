@@ -10,6 +10,7 @@
 // and dL/d(exposure a, b): workgroup partials are summed in workgroup order, in fp64, by the last-arriving
 // workgroup (ticket; no float atomics).
 #include "gsaj_common.h"
+#include "loss_terms.h"
 
 #define LOSS_BLOCK 256
 #define LOSS_PPT 4  // pixels per thread (strided by the workgroup size: coalesced, 4x the loads in flight, 4x fewer partials)
@@ -28,7 +29,7 @@ struct LossParams {
   size_t ws_stride;   // batched launch (gridDim.y = views): bytes between consecutive views' workspace blocks
 };
 
-__device__ __forceinline__ float sgn(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
+__device__ __forceinline__ float sgn(float x) { return loss_sgn(x); }
 
 __global__ __launch_bounds__(LOSS_BLOCK) void k_loss_seeds(LossParams p) {
   __shared__ float red[4][LOSS_BLOCK / 64];
@@ -49,14 +50,12 @@ __global__ __launch_bounds__(LOSS_BLOCK) void k_loss_seeds(LossParams p) {
     p.ticket = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(p.ticket) + v * p.ws_stride);
     p.n_valid = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(p.n_valid) + v * p.ws_stride);
   }
-  const bool tracking = p.flags & GSAJ_LOSS_TRACKING, mono = p.flags & GSAJ_LOSS_MONOCULAR, noexp = p.flags & GSAJ_LOSS_NO_EXPOSURE;
+  const bool mono = p.flags & GSAJ_LOSS_MONOCULAR, noexp = p.flags & GSAJ_LOSS_NO_EXPOSURE;
   // compute_loss of the verification harness (Jacobian_test.py:155-196): mask given per pixel, colour term = mean over
   // 3HW, depth term = mean over the valid pixels only, plain sum of the two (no alpha weighting, no exposure)
   const bool cl = p.flags & GSAJ_LOSS_COMPUTE_LOSS;
-  const float ea = noexp ? 1.f : expf(p.exp_a[0]), eb = noexp ? 0.f : p.exp_b[0];
-  const float nv = cl ? (float)max(p.n_valid[0], 1u) : 0.f;
-  const float k_rgb = cl ? 1.f / (3.f * (float)HW) : (mono ? 1.f : p.alpha) / (3.f * (float)HW);
-  const float k_d = cl ? 1.f / nv : (1.f - p.alpha) / (float)HW;
+  const LossConsts L = loss_consts(p.flags, p.alpha, p.rgb_thr, p.exp_a, p.exp_b, HW, cl ? (float)max(p.n_valid[0], 1u) : 1.f);
+  const float k_rgb = L.k_rgb;
   float s_rgb = 0.f, s_d = 0.f, s_a = 0.f, s_b = 0.f;
 #pragma unroll
   for (int q = 0; q < LOSS_PPT; q++) {
@@ -65,30 +64,15 @@ __global__ __launch_bounds__(LOSS_BLOCK) void k_loss_seeds(LossParams p) {
     const float g0 = p.gt_color[pix], g1 = p.gt_color[HW + pix], g2 = p.gt_color[2 * HW + pix];
     const float c0 = p.color[pix], c1 = p.color[HW + pix], c2 = p.color[2 * HW + pix];
     const float op = p.opacity[pix];
-    float m = (cl || g0 + g1 + g2 > p.rgb_thr) ? 1.f : 0.f;
-    if ((tracking || cl) && p.grad_mask) m = p.grad_mask[pix] ? m : 0.f;
-    const float wrgb = tracking ? op : 1.f;
-    const float r0 = (ea * c0 + eb) * m - g0 * m, r1 = (ea * c1 + eb) * m - g1 * m, r2 = (ea * c2 + eb) * m - g2 * m;
-    const float a0 = fabsf(r0), a1 = fabsf(r1), a2 = fabsf(r2);
-    const float t0 = wrgb * m * sgn(r0), t1 = wrgb * m * sgn(r1), t2 = wrgb * m * sgn(r2);
-    s_rgb += wrgb * (a0 + a1 + a2);
-    p.dL_dcolor[pix] = k_rgb * ea * t0;
-    p.dL_dcolor[HW + pix] = k_rgb * ea * t1;
-    p.dL_dcolor[2 * HW + pix] = k_rgb * ea * t2;
-    if (p.dL_dopacity) p.dL_dopacity[pix] = tracking ? k_rgb * (a0 + a1 + a2) : 0.f;
-    s_a += ea * (t0 * c0 + t1 * c1 + t2 * c2);
-    s_b += t0 + t1 + t2;
-    float dd = 0.f;
-    if (!mono) {
-      const float gd = p.gt_depth[pix], d = p.depth[pix];
-      float dm = (gd > (cl ? 0.0f : 0.01f)) ? 1.f : 0.f;
-      if (tracking) dm = (op > 0.95f) ? dm : 0.f;
-      if (cl) dm *= m;
-      const float rd = d * dm - gd * dm;
-      s_d += fabsf(rd);
-      dd = k_d * dm * sgn(rd);
-    }
-    p.dL_ddepth[pix] = dd;
+    const bool mask = p.grad_mask ? p.grad_mask[pix] != 0 : true;
+    const float gd = mono ? 0.f : p.gt_depth[pix], d = mono ? 0.f : p.depth[pix];
+    const LossPixel o = loss_pixel(L, g0, g1, g2, c0, c1, c2, op, mask, gd, d);  // (loss_terms.h: shared with the fused compositors)
+    s_rgb += o.s_rgb; s_d += o.s_d; s_a += o.s_a; s_b += o.s_b;
+    p.dL_dcolor[pix] = o.gC0;
+    p.dL_dcolor[HW + pix] = o.gC1;
+    p.dL_dcolor[2 * HW + pix] = o.gC2;
+    if (p.dL_dopacity) p.dL_dopacity[pix] = o.dop;
+    p.dL_ddepth[pix] = o.gD;
   }
   // workgroup partials: wave butterfly, then the four waves in order
   float v[4] = {s_rgb, s_d, s_a, s_b};
@@ -153,6 +137,46 @@ __global__ __launch_bounds__(LOSS_BLOCK) void k_loss_seeds(LossParams p) {
     p.out[4] = noexp ? 0.f : (float)((double)k_rgb * t[3]);
     *p.ticket = 0u;
   }
+}
+
+// The loss value and dL/d(exposure) of a frame whose forward compositor summed the per-pixel terms itself (render_fwd.hip,
+// loss-fused form): one workgroup adds the per-workgroup partials in slot order (fp64, fixed tree) -- the tail of k_loss_seeds
+// without its pass over the image.
+__global__ __launch_bounds__(LOSS_BLOCK) void k_loss_finalize(FusedLoss fl, int nslots, size_t HW, const uint32_t *__restrict__ aborted,
+                                                              float *__restrict__ out) {
+  __shared__ double red[4][LOSS_BLOCK];
+  if (aborted && aborted[0]) return;  // aborted asynchronous frame: no partials were written; the scalars stay the last frame's
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int b = threadIdx.x; b < nslots; b += LOSS_BLOCK) {
+    const float4 v = reinterpret_cast<const float4 *>(fl.partials)[b];
+    acc[0] += (double)v.x; acc[1] += (double)v.y; acc[2] += (double)v.z; acc[3] += (double)v.w;
+  }
+#pragma unroll
+  for (int c = 0; c < 4; c++) red[c][threadIdx.x] = acc[c];
+  __syncthreads();
+  for (int o = LOSS_BLOCK / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+#pragma unroll
+      for (int c = 0; c < 4; c++) red[c][threadIdx.x] += red[c][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const bool mono = fl.flags & GSAJ_LOSS_MONOCULAR, noexp = fl.flags & GSAJ_LOSS_NO_EXPOSURE;
+    const LossConsts L = loss_consts(fl.flags, fl.alpha, fl.rgb_thr, fl.exp_a, fl.exp_b, HW, 1.f);
+    const double l_rgb = red[0][0] / (3.0 * (double)HW), l_d = mono ? 0.0 : red[1][0] / (double)HW;
+    out[0] = (float)(mono ? l_rgb : (double)fl.alpha * l_rgb + (1.0 - (double)fl.alpha) * l_d);
+    out[1] = (float)l_rgb;
+    out[2] = (float)l_d;
+    out[3] = noexp ? 0.f : (float)((double)L.k_rgb * red[2][0]);
+    out[4] = noexp ? 0.f : (float)((double)L.k_rgb * red[3][0]);
+  }
+}
+
+int launch_loss_finalize(const FusedLoss &fl, int nslots, int W, int H, const uint32_t *aborted, float *out_scalars, hipStream_t s) {
+  hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(LOSS_BLOCK), 0, s, fl, nslots, (size_t)W * H, aborted, out_scalars);
+  GSAJ_HIP_CHECK(hipGetLastError());
+  return GSAJ_OK;
 }
 
 // number of pixels with gt_depth > 0 inside the mask (the denominator of compute_loss's depth term): integer atomics

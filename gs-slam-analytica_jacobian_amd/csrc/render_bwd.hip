@@ -33,6 +33,7 @@
 //  last contributor keep the one-byte `reached = 0` flag the tile sort gave them instead of a zero row.
 //  Workgroups take tiles longest list first (ImageWS.tile_order, written by the preprocess kernel's frame scan).
 #include "gsaj_common.h"
+#include "loss_terms.h"
 #include "wave_reduce.h"
 
 #define BWD_ROUND 48   // list entries staged per workgroup round: 30.8 KB LDS + 96 VGPRs = five resident workgroups per CU (all 1200 tiles of a 640x480 frame at once)
@@ -43,12 +44,17 @@
 
 GSAJ_TRACE_DEFINE(bwd)
 
+// LOSS: the loss-fused form (gsaj_rasterize_backward_loss): a pixel's seeds dL/dC, dL/dD are derived in the
+// prologue from the images the forward wrote and the ground truth (loss_terms.h: the stand-alone loss kernel's arithmetic, same
+// bits) instead of being read from a seed image -- that image is never materialised.
+template <bool LOSS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_render_bwd(int W, int H, int gx, ImageWS im,
                                                     const uint32_t *__restrict__ point_list, GeomWS g,
                                                     const float *__restrict__ bg,
                                                     const float *__restrict__ dL_dpix,
                                                     const float *__restrict__ dL_dpix_depth,
-                                                    float4 *__restrict__ inst_grad, uint8_t *__restrict__ reached, ViewStrides vs) {
+                                                    float4 *__restrict__ inst_grad, uint8_t *__restrict__ reached, ViewStrides vs,
+                                                    FusedLoss fl) {
   {  // batched launch: blockIdx.y = view
     const size_t view = blockIdx.y, HWv = (size_t)H * W;
     im = image_view(im, view * vs.image);
@@ -90,10 +96,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
   const uint32_t last = inside ? n_contrib[pid] : 0u;
   float gC0 = 0.f, gC1 = 0.f, gC2 = 0.f, gD = 0.f;
   if (inside) {
-    gC0 = dL_dpix[pid];
-    gC1 = dL_dpix[HW + pid];
-    gC2 = dL_dpix[2 * HW + pid];
-    gD = dL_dpix_depth[pid];
+    if (LOSS) {
+      const LossConsts L = loss_consts(fl.flags, fl.alpha, fl.rgb_thr, fl.exp_a, fl.exp_b, HW, 1.f);
+      const bool mask = fl.grad_mask ? fl.grad_mask[pid] != 0 : true;
+      const float gd = L.mono ? 0.f : fl.gt_depth[pid], d = L.mono ? 0.f : fl.depth[pid];
+      const LossPixel o = loss_pixel(L, fl.gt_color[pid], fl.gt_color[HW + pid], fl.gt_color[2 * HW + pid], fl.color[pid], fl.color[HW + pid],
+                                     fl.color[2 * HW + pid], fl.opacity[pid], mask, gd, d);
+      gC0 = o.gC0; gC1 = o.gC1; gC2 = o.gC2; gD = o.gD;
+    } else {
+      gC0 = dL_dpix[pid];
+      gC1 = dL_dpix[HW + pid];
+      gC2 = dL_dpix[2 * HW + pid];
+      gD = dL_dpix_depth[pid];
+    }
   }
   seed[lane] = make_float4(gC0, gC1, gC2, gD);
   const float Tf_bg = T_final * (bg[0] * gC0 + bg[1] * gC1 + bg[2] * gC2);
@@ -307,12 +322,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 
 int launch_render_backward(int R, int W, int H, int grid_x, int grid_y, const float *bg, const GeomWS &g, const BinWS &b,
                            const ImageWS &im, const float *dL_dpix, const float *dL_dpix_depth, int views, ViewStrides vs,
-                           hipStream_t s) {
+                           hipStream_t s, const FusedLoss *fl) {
   if (R <= 0) return GSAJ_OK;  // (async callers pass the arena capacity as R)
   {
     GsajProfScope ps(ST_RENDER_BWD, s);
-    hipLaunchKernelGGL(k_render_bwd, dim3(grid_x * grid_y, views), dim3(256), 0, s, W, H, grid_x, im, b.point_list, g, bg, dL_dpix,
-                       dL_dpix_depth, b.inst_grad, b.reached, vs);
+    if (fl)
+      hipLaunchKernelGGL(k_render_bwd<true>, dim3(grid_x * grid_y, 1), dim3(256), 0, s, W, H, grid_x, im, b.point_list, g, bg, dL_dpix,
+                         dL_dpix_depth, b.inst_grad, b.reached, vs, *fl);
+    else
+      hipLaunchKernelGGL(k_render_bwd<false>, dim3(grid_x * grid_y, views), dim3(256), 0, s, W, H, grid_x, im, b.point_list, g, bg, dL_dpix,
+                         dL_dpix_depth, b.inst_grad, b.reached, vs, FusedLoss{});
   }
   GSAJ_HIP_CHECK(hipGetLastError());
   return GSAJ_OK;

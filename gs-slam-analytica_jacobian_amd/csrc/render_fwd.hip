@@ -15,6 +15,7 @@
 // quadrant still has T > 0.5, and ONE atomic wave-instruction per 64 entries flushes it (the reference issues one
 // atomic per pixel per entry, forward.cu:512-514).  Tiles are taken longest list first (ImageWS.tile_order).
 #include "gsaj_common.h"
+#include "loss_terms.h"
 #include "wave_reduce.h"
 
 #define FWD_CHUNK 64  // records staged per wave per trip
@@ -32,12 +33,16 @@
 
 GSAJ_TRACE_DEFINE(fwd)
 
+// LOSS: the loss-fused form (gsaj_rasterize_forward_loss): the epilogue also evaluates the tracking / mapping
+// L1 terms of its pixels against the ground truth (loss_terms.h) and leaves the workgroup's four sums in fl.partials -- the loss
+// value without a pass of its own over the images.
+template <bool LOSS>
 __global__ __launch_bounds__(GSAJ_FWD_THREADS) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_render_fwd(int W, int H, int gx, int tiles, int P, ImageWS im,
                                                     const float4 *__restrict__ splat, const float4 *__restrict__ splat16,
                                                     const float *__restrict__ bg,
                                                     float *__restrict__ out_color, float *__restrict__ out_depth,
                                                     float *__restrict__ out_opacity, int *__restrict__ n_touched,
-                                                    const uint32_t *__restrict__ point_list, ViewStrides vs) {
+                                                    const uint32_t *__restrict__ point_list, ViewStrides vs, FusedLoss fl) {
   {  // batched launch: blockIdx.y = view
     const size_t view = blockIdx.y, HWv = (size_t)H * W;
     im = image_view(im, view * vs.image);
@@ -64,7 +69,10 @@ __global__ __launch_bounds__(GSAJ_FWD_THREADS) __attribute__((amdgpu_waves_per_e
   // 32 consecutive workgroups = 8 tiles x 4 quadrants; tile slot = blockIdx.x & 7 (the XCD the workgroup lands on)
   const int wave = ((int)blockIdx.x >> 3) & 3;
   const int rank = ((int)blockIdx.x >> 5) * 8 + ((int)blockIdx.x & 7);
-  if (rank >= tiles) return;
+  if (rank >= tiles) {
+    if (LOSS && lane == 0) reinterpret_cast<float4 *>(fl.partials)[blockIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
   const int tile = (int)min(im.tile_order[rank], (uint32_t)(tiles - 1));  // longest lists first (frame_scan)
   float4 *rec = rec_all;
 #else
@@ -208,18 +216,46 @@ __global__ __launch_bounds__(GSAJ_FWD_THREADS) __attribute__((amdgpu_waves_per_e
     out_depth[pid] = Dp;
     out_opacity[pid] = 1.f - T;
   }
+  if (LOSS) {  // the loss terms of this quadrant's pixels, from the very values just stored
+    float s4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (inside) {
+      const size_t pid = (size_t)py * W + px, HW = (size_t)H * W;
+      const LossConsts L = loss_consts(fl.flags, fl.alpha, fl.rgb_thr, fl.exp_a, fl.exp_b, HW, 1.f);
+      const bool mask = fl.grad_mask ? fl.grad_mask[pid] != 0 : true;
+      const float gd = L.mono ? 0.f : fl.gt_depth[pid];
+      const LossPixel o = loss_pixel(L, fl.gt_color[pid], fl.gt_color[HW + pid], fl.gt_color[2 * HW + pid], Cr + T * bg[0], Cg + T * bg[1],
+                                     Cb + T * bg[2], 1.f - T, mask, gd, Dp);
+      s4[0] = o.s_rgb; s4[1] = o.s_d; s4[2] = o.s_a; s4[3] = o.s_b;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+#pragma unroll
+      for (int o2 = 32; o2 > 0; o2 >>= 1) s4[c] += __shfl_xor(s4[c], o2);
+    }
+    if (lane == 0) reinterpret_cast<float4 *>(fl.partials)[blockIdx.x] = make_float4(s4[0], s4[1], s4[2], s4[3]);
+  }
   GSAJ_TRACE_END(fwd)
+}
+
+int gsaj_fwd_loss_slots(int W, int H) {
+  const int tiles = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+  return FWD_WAVES == 1 ? ((tiles + 7) / 8) * 32 : tiles;
 }
 
 int launch_render_forward(int P, int W, int H, int grid_x, int grid_y, const float *bg, const GeomWS &g, const BinWS &b,
                           const ImageWS &im, float *out_color, float *out_depth, float *out_opacity, int *n_touched, int views,
-                          ViewStrides vs, hipStream_t s) {
+                          ViewStrides vs, hipStream_t s, const FusedLoss *fl) {
+  static_assert(FWD_WAVES == 1, "the loss-fused epilogue writes one partial per wave-sized workgroup");
   {
     GsajProfScope ps(ST_RENDER_FWD, s);
     const int tiles = grid_x * grid_y;
     const unsigned nblk = FWD_WAVES == 1 ? (unsigned)((tiles + 7) / 8) * 32u : (unsigned)tiles;
-    hipLaunchKernelGGL(k_render_fwd, dim3(nblk, views), dim3(GSAJ_FWD_THREADS), 0, s, W, H, grid_x, tiles, P, im, g.splat, g.splat16, bg, out_color,
-                       out_depth, out_opacity, n_touched, b.point_list, vs);
+    if (fl)
+      hipLaunchKernelGGL(k_render_fwd<true>, dim3(nblk, 1), dim3(GSAJ_FWD_THREADS), 0, s, W, H, grid_x, tiles, P, im, g.splat, g.splat16, bg,
+                         out_color, out_depth, out_opacity, n_touched, b.point_list, vs, *fl);
+    else
+      hipLaunchKernelGGL(k_render_fwd<false>, dim3(nblk, views), dim3(GSAJ_FWD_THREADS), 0, s, W, H, grid_x, tiles, P, im, g.splat, g.splat16,
+                         bg, out_color, out_depth, out_opacity, n_touched, b.point_list, vs, FusedLoss{});
   }
   GSAJ_HIP_CHECK(hipGetLastError());
   return GSAJ_OK;

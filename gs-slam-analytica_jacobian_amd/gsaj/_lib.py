@@ -36,6 +36,12 @@ SIGNATURES = {
                                              c_float, c_float, c_int, P, P, P, P, P, P, P, c_size_t, c_int, c_int, P, c_int, P]),
     "gsaj_rasterize_backward_batch": (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, c_int, P, P, P, P, c_float, P, P, P, P,
                                               P, P, c_float, c_float, P, P, P, P, P, P] + [P] * 12 + [c_int, P]),
+    "gsaj_fused_loss_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "gsaj_rasterize_forward_loss": (c_int, [c_int, c_int, c_int, P, c_int, c_int, P, P, P, P, P, c_float, P, P, P, P, P,
+                                            c_float, c_float, c_int, P, P, P, P, P, P, P, c_size_t, c_int, c_int, P, c_int,
+                                            c_int, c_float, c_float, P, P, P, P, P, P, P, P]),
+    "gsaj_rasterize_backward_loss": (c_int, [c_int, c_int, c_int, c_int, P, c_int, c_int, P, P, P, P, c_float, P, P, P, P, P, P,
+                                             c_float, c_float, P, P, P, P, c_int, c_float, c_float, P, P, P, P, P, P, P, P] + [P] * 12 + [P]),
     "gsaj_forward_aborted_count": (c_int, [c_int, c_int, P, P, ctypes.POINTER(c_int)]),
     "gsaj_set_tile_band": (c_int, [c_int, c_int, P, c_int, c_int, P]),
     "gsaj_forward_preprocess_cap": (c_int, [c_int] * 5 + [P, P, P, P, P, c_float, P, P, P, P, P, c_float, c_float, c_int, P, P,

@@ -376,6 +376,52 @@ class FrameContext:
             self.depth.data_ptr(), self.opacity.data_ptr(), self.n_touched.data_ptr(), self.flags, st), "gsaj_forward_render")
         return self.R
 
+    # ---- the loss fused into the compositors (gsaj_rasterize_forward_loss / _backward_loss) -----------------
+    def forward_loss(self, loss, bg, means3D, opacities, viewmatrix, projmatrix, campos, tanfovx, tanfovy, sh_degree=0, shs=None,
+                     colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, scale_modifier=1.0):
+        """Asynchronous forward (the arena must have been sized by a synchronous forward()) whose compositor also sums the loss:
+        loss = dict(flags, alpha, rgb_boundary_threshold, gt_color [3,H,W], gt_depth [H,W] or None, grad_mask (uint8 [H*W]) or None,
+        exposure_a, exposure_b (device scalars or None), scalars (float32 [5] device: loss, L_rgb, L_depth, dL/da, dL/db))."""
+        if self.capacity <= 0:
+            raise _lib.GsajError("forward_loss: size the arena with one synchronous forward() first")
+        if not hasattr(self, "loss_ws"):
+            self.loss_ws = torch.empty(self.lib.gsaj_fused_loss_workspace_bytes(self.W, self.H), device=self.dev, dtype=torch.uint8)
+        with torch.cuda.device(self.dev):
+            _lib.check(self.lib.gsaj_rasterize_forward_loss(
+                self.P, int(sh_degree), self.M, _ptr(bg), self.W, self.H, _ptr(means3D), _ptr(shs), _ptr(colors_precomp),
+                _ptr(opacities), _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp),
+                _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), float(tanfovx), float(tanfovy), 0,
+                self.color.data_ptr(), self.depth.data_ptr(), self.opacity.data_ptr(), self.radii.data_ptr(),
+                self.n_touched.data_ptr(), self.geom.data_ptr(), self.binning.data_ptr(), self.binning.numel(),
+                self.capacity, self.tile_list_capacity, self.img.data_ptr(), self.flags, int(loss["flags"]), float(loss["alpha"]),
+                float(loss["rgb_boundary_threshold"]), _ptr(loss["gt_color"]), _ptr(loss.get("gt_depth")), _ptr(loss.get("grad_mask")),
+                _ptr(loss.get("exposure_a")), _ptr(loss.get("exposure_b")), loss["scalars"].data_ptr(), self.loss_ws.data_ptr(),
+                _stream(self.dev)), "gsaj_rasterize_forward_loss")
+        self.R = self.capacity
+        return self.R
+
+    def backward_loss(self, loss, bg, means3D, viewmatrix, projmatrix, projmatrix_raw, campos, tanfovx, tanfovy, sh_degree=0, shs=None,
+                      colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, scale_modifier=1.0, slot=0,
+                      pose_only=False):
+        """backward() with the pixel seeds derived inside the reverse compositor from this context's color / depth / opacity and the
+        ground truth of `loss` (same dict as forward_loss): no dL/dcolor, dL/ddepth images exist."""
+        g = self.slots[slot]
+        if g["tau_all"] is not None:
+            g["tau_all"].zero_()
+        with torch.cuda.device(self.dev):
+            _lib.check(self.lib.gsaj_rasterize_backward_loss(
+                self.P, int(sh_degree), self.M, self.R, _ptr(bg), self.W, self.H, _ptr(means3D), _ptr(shs),
+                _ptr(colors_precomp), _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp),
+                _ptr(viewmatrix), _ptr(projmatrix), _ptr(projmatrix_raw), _ptr(campos), float(tanfovx), float(tanfovy),
+                self.radii.data_ptr(), self.geom.data_ptr(), self.binning.data_ptr(), self.img.data_ptr(), int(loss["flags"]),
+                float(loss["alpha"]), float(loss["rgb_boundary_threshold"]), self.color.data_ptr(), self.depth.data_ptr(),
+                self.opacity.data_ptr(), _ptr(loss["gt_color"]), _ptr(loss.get("gt_depth")), _ptr(loss.get("grad_mask")),
+                _ptr(loss.get("exposure_a")), _ptr(loss.get("exposure_b")), *([None] * 10 if pose_only else [
+                    g["mean2D"].data_ptr(), g["conic"].data_ptr(), g["opacity"].data_ptr(), g["color"].data_ptr(),
+                    g["depth"].data_ptr(), g["mean3D"].data_ptr(), g["cov3D"].data_ptr(), _ptr(g["sh"]), _ptr(g["scale"]),
+                    _ptr(g["rot"])]), _ptr(g["tau"]), g["tau_sum"].data_ptr(), _stream(self.dev)), "gsaj_rasterize_backward_loss")
+        return g
+
     def backward(self, bg, means3D, viewmatrix, projmatrix, projmatrix_raw, campos, tanfovx, tanfovy, dL_dcolor, dL_ddepth,
                  sh_degree=0, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None,
                  scale_modifier=1.0, slot=0, pose_only=False):

@@ -32,9 +32,12 @@ from .rasterizer import FrameContext
 class DeviceTracker:
     def __init__(self, P, W, H, M, device, w2c, projection_matrix, tanfovx, tanfovy, bg, means3D, opacities, sh_degree=0, shs=None,
                  colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None, monocular=False, alpha=0.95,
-                 rgb_boundary_threshold=0.01, record_bits=32, band=None, group=None, use_graph=False, **pose_kw):
+                 rgb_boundary_threshold=0.01, record_bits=32, band=None, group=None, use_graph=False, fused=True, **pose_kw):
         """The Gaussians (device tensors) are those of the current map: the loop reads them, it never writes them.  pose_kw:
-        learning rates / betas / eps / converged_threshold of PoseTracker (config["Training"]["lr"] in the reference)."""
+        learning rates / betas / eps / converged_threshold of PoseTracker (config["Training"]["lr"] in the reference).
+        fused=True (default): the loss is evaluated inside the compositors (gsaj_rasterize_forward_loss / _backward_loss): the
+        forward's epilogue sums the loss terms, the reverse compositor derives its pixel seeds itself -- no loss kernel, no seed
+        images; the pose follows the unfused loop bit for bit (same per-pixel arithmetic), the loss scalars to rounding."""
         self.dev = torch.device(device)
         if self.dev.type != "cuda":
             raise _lib.GsajError("DeviceTracker needs a HIP device (there is no CPU path)")
@@ -50,7 +53,7 @@ class DeviceTracker:
         self.bg, self.means, self.opac = bg, means3D, opacities
         self.kw = dict(sh_degree=sh_degree, shs=shs, colors_precomp=colors_precomp, scales=scales, rotations=rotations,
                        cov3D_precomp=cov3D_precomp)
-        self.group, self.use_graph = group, bool(use_graph)
+        self.group, self.use_graph, self.fused = group, bool(use_graph), bool(fused)
         # dL/dtau and the loss kernel's five scalars land side by side in ONE buffer (the backward and gsaj_loss_seeds are handed
         # views of it): nothing to pack before the all-reduce / the pose step -- three launches fewer per iteration
         self.packed = torch.zeros(tbs.REDUCED_FLOATS, dtype=torch.float32, device=self.dev)
@@ -65,6 +68,16 @@ class DeviceTracker:
     # ---- one iteration, in the two halves a collective may sit between -------------------------------------------------
     def _render_and_grads(self, sync):
         p, c = self.pose, self.ctx
+        if self.fused and not sync:
+            L = dict(flags=self.flags, alpha=self.alpha, rgb_boundary_threshold=self.thr, gt_color=self.gt_color, gt_depth=self.gt_depth,
+                     grad_mask=self.grad_mask, exposure_a=p.exposure_a, exposure_b=p.exposure_b, scalars=self.packed[6:11])
+            c.forward_loss(L, self.bg, self.means, self.opac, p.viewmatrix, p.projmatrix, p.campos, self.tanfov[0], self.tanfov[1], **self.kw)
+            g = c.backward_loss(L, self.bg, self.means, p.viewmatrix, p.projmatrix, self.praw, p.campos, self.tanfov[0], self.tanfov[1],
+                                pose_only=True, **self.kw)
+            assert g["tau_sum"].data_ptr() == self.packed.data_ptr()
+            if self._sharded():
+                self.packed[tbs.ABORTED].copy_(self._abort_word)
+            return
         c.forward(self.bg, self.means, self.opac, p.viewmatrix, p.projmatrix, p.campos, self.tanfov[0], self.tanfov[1], sync=sync,
                   **self.kw)
         L = self.loss(self.flags, self.alpha, self.thr, c.color, c.depth, c.opacity, self.gt_color, self.gt_depth, self.grad_mask,

@@ -278,6 +278,39 @@ int gsaj_loss_seeds(int W, int H, int flags, float alpha, float rgb_boundary_thr
                     const uint8_t *grad_mask, const float *exposure_a, const float *exposure_b, float *dL_dcolor,
                     float *dL_ddepth, float *dL_dopacity, float *out_scalars, void *loss_ws, void *stream);
 
+/* ---- the same losses FUSED into the compositors (SURVEY 8(f)-1 as written): no seed image, no pass over the frame ------------
+ * The reference evaluates get_loss_tracking / get_loss_mapping between render() and backward() (utils/slam_frontend.py:164-176,
+ * utils/slam_utils.py:56-128).  gsaj_rasterize_forward_loss = gsaj_rasterize_forward_async whose compositor epilogue also sums the
+ * loss terms of its pixels against the ground truth; out_scalars[5] = {loss, L_rgb, L_depth, dL/da, dL/db} (device) are there when
+ * the call's work has run.  gsaj_rasterize_backward_loss = gsaj_rasterize_backward whose reverse compositor derives each pixel's
+ * seeds dL/dC, dL/dD from the images the forward wrote (color, depth, opacity: pass them back), the ground truth and the exposure
+ * scalars, with the arithmetic of gsaj_loss_seeds bit for bit -- the gradients equal those of forward -> gsaj_loss_seeds ->
+ * backward exactly; the loss scalars differ from gsaj_loss_seeds' only by the order of their sums.  loss_flags: GSAJ_LOSS_TRACKING,
+ * _MONOCULAR, _NO_EXPOSURE (GSAJ_LOSS_COMPUTE_LOSS has no fused form).  loss_ws: gsaj_fused_loss_workspace_bytes(W, H) bytes, no
+ * initialisation needed.  An aborted frame leaves out_scalars as they were. */
+size_t gsaj_fused_loss_workspace_bytes(int W, int H);
+int gsaj_rasterize_forward_loss(int P, int D, int M, const float *bg, int W, int H, const float *means3D, const float *shs,
+                                const float *colors_precomp, const float *opacities, const float *scales, float scale_modifier,
+                                const float *rotations, const float *cov3D_precomp, const float *viewmatrix,
+                                const float *projmatrix, const float *campos, float tanfovx, float tanfovy, int prefiltered,
+                                float *out_color, float *out_depth, float *out_opacity, int *radii, int *n_touched, void *geom_ws,
+                                void *binning_ws, size_t binning_ws_bytes, int capacity, int tile_list_capacity, void *image_ws,
+                                int flags /* GSAJ_FWD_* */, int loss_flags /* GSAJ_LOSS_* */, float alpha,
+                                float rgb_boundary_threshold, const float *gt_color /*dev [3,H,W]*/,
+                                const float *gt_depth /*dev [H,W] or NULL (monocular)*/, const uint8_t *grad_mask /*dev [H,W] or NULL*/,
+                                const float *exposure_a, const float *exposure_b /*dev scalars; NULL with NO_EXPOSURE*/,
+                                float *out_scalars /*dev [5]*/, void *loss_ws, void *stream);
+int gsaj_rasterize_backward_loss(int P, int D, int M, int R, const float *bg, int W, int H, const float *means3D, const float *shs,
+                                 const float *colors_precomp, const float *scales, float scale_modifier, const float *rotations,
+                                 const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix,
+                                 const float *projmatrix_raw, const float *campos, float tanfovx, float tanfovy, const int *radii,
+                                 void *geom_ws, void *binning_ws, void *image_ws, int loss_flags, float alpha,
+                                 float rgb_boundary_threshold, const float *color, const float *depth, const float *opacity,
+                                 const float *gt_color, const float *gt_depth, const uint8_t *grad_mask, const float *exposure_a,
+                                 const float *exposure_b, float *dL_dmean2D, float *dL_dconic, float *dL_dopacity, float *dL_dcolor,
+                                 float *dL_ddepth, float *dL_dmean3D, float *dL_dcov3D, float *dL_dsh, float *dL_dscale,
+                                 float *dL_drot, float *dL_dtau, float *dL_dtau_sum, void *stream);
+
 /* The same for the K views of a mapping window in ONE launch (utils/slam_backend.py:168-232 sums get_loss_mapping over the
  * keyframes of the window): color / gt_color / dL_dcolor [K,3,H,W], depth / opacity / dL_ddepth / dL_dopacity [K,1,H,W], gt_depth /
  * grad_mask [K,H,W], exposure_a / exposure_b [K] (one pair per keyframe, camera_utils.py:43-48), out_scalars [K,5]; view k gets

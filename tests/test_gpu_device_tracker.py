@@ -146,3 +146,70 @@ def test_arena_overflow_is_reported_and_the_next_call_recovers():
     tr.set_frame(gt_c, gt_d, w2c=w2c0)
     assert tr.iterate(2) == 2  # re-sized by a synchronous first iteration, graph re-captured if the arena moved
     assert torch.equal(tr.w2c, good)
+
+
+@pytest.mark.parametrize("monocular,masked", [(False, False), (False, True), (True, False)])
+def test_loss_fused_into_the_compositors_gives_the_unfused_gradients_bit_for_bit(monocular, masked):
+    """SURVEY 8(f)-1 as written: gsaj_rasterize_forward_loss sums the tracking loss in the forward compositor's epilogue,
+    gsaj_rasterize_backward_loss derives the pixel seeds in the reverse compositor's prologue -- no loss kernel, no seed images.
+    Against forward -> gsaj_loss_seeds -> backward on the same frame: EVERY gradient output identical bit for bit (the seeds
+    come from one shared definition of the per-pixel arithmetic, csrc/loss_terms.h), the five loss scalars equal to rounding
+    (they are sums in a different order).  gsaj_loss_seeds itself is pinned to the reference's get_loss_tracking under
+    autograd (tests/test_gpu_loss.py, loss_*.npz)."""
+    import torch
+    from gsaj.losses import MONOCULAR, TRACKING, LossSeeds
+    from gsaj.rasterizer import FrameContext
+
+    dev, cam, g, bg, gt_c, gt_d, w2c0, M, praw = _setup()
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)  # noqa: E731
+    P, W, H = g["means3D"].shape[0], cam["W"], cam["H"]
+    view, proj, cp = t(cam["viewmatrix"]), t(cam["projmatrix"]), t(cam["campos"])
+    kw = dict(sh_degree=3, shs=g["shs"], scales=g["scales"], rotations=g["rotations"])
+    ea, eb = torch.tensor([0.07], device=dev), torch.tensor([-0.02], device=dev)
+    mask = None
+    if masked:
+        mask = (torch.rand(H * W, device=dev, generator=torch.Generator(device=dev).manual_seed(5)) > 0.3).to(torch.uint8)
+    flags = TRACKING | (MONOCULAR if monocular else 0)
+    gtd = None if monocular else gt_d.contiguous()
+
+    a = FrameContext(P, W, H, M, dev, per_gaussian_tau=True)
+    a.forward(bg, g["means3D"], g["opacities"], view, proj, cp, cam["tanfovx"], cam["tanfovy"], sync=True, **kw)
+    a.forward(bg, g["means3D"], g["opacities"], view, proj, cp, cam["tanfovx"], cam["tanfovy"], sync=False, **kw)
+    ls = LossSeeds(W, H, dev)
+    L = ls(flags, 0.9, 0.01, a.color, a.depth, a.opacity, gt_c, gtd, mask, ea, eb)
+    ga = a.backward(bg, g["means3D"], view, proj, praw, cp, cam["tanfovx"], cam["tanfovy"], L["dL_dcolor"], L["dL_ddepth"], **kw)
+    want = {n: x.clone() for n, x in ga.items() if torch.is_tensor(x)}
+    want_scalars = ls.scalars.clone()
+    assert float(want["tau_sum"].abs().max()) > 0.0
+
+    b = FrameContext(P, W, H, M, dev, per_gaussian_tau=True)
+    b.forward(bg, g["means3D"], g["opacities"], view, proj, cp, cam["tanfovx"], cam["tanfovy"], sync=True, **kw)
+    scalars = torch.zeros(5, device=dev)
+    FL = dict(flags=flags, alpha=0.9, rgb_boundary_threshold=0.01, gt_color=gt_c, gt_depth=gtd, grad_mask=mask, exposure_a=ea, exposure_b=eb,
+              scalars=scalars)
+    b.forward_loss(FL, bg, g["means3D"], g["opacities"], view, proj, cp, cam["tanfovx"], cam["tanfovy"], **kw)
+    gb = b.backward_loss(FL, bg, g["means3D"], view, proj, praw, cp, cam["tanfovx"], cam["tanfovy"], **kw)
+    assert torch.equal(a.color, b.color) and torch.equal(a.depth, b.depth) and torch.equal(a.n_touched, b.n_touched)
+    for n, x in want.items():
+        assert torch.equal(gb[n], x), "dL/d%s of the fused path differs from the unfused path" % n
+    assert float((scalars - want_scalars).abs().max()) <= 2e-6 * float(want_scalars.abs().max()), (scalars, want_scalars)
+
+
+def test_fused_tracker_follows_the_unfused_tracker_bit_for_bit():
+    """DeviceTracker(fused=True), the default: an iteration is forward_loss -> backward_loss -> pose step, with no dL/dpix buffers;
+    the pose after 10 iterations equals the unfused tracker's bit for bit (the pose step consumes dL/dtau and dL/d(exposure), both
+    functions of the per-pixel seeds... dL/d(exposure) is a SUM of pixel terms in another order: the exposure learning rates are
+    set to zero here so that the comparison is exact; with them on, the poses agree to 1e-6)."""
+    import torch
+
+    dev, cam, g, bg, gt_c, gt_d, w2c0, M, praw = _setup()
+    out = {}
+    for fused in (False, True):
+        for lr_exp in (0.0, 0.01):
+            tr = _tracker(dev, cam, g, bg, w2c0, M, praw, use_graph=False, fused=fused, lr_exposure_a=lr_exp, lr_exposure_b=lr_exp)
+            tr.set_frame(gt_c, gt_d)
+            assert tr.iterate(10) == 10
+            out[fused, lr_exp] = (tr.w2c.clone(), tr.loss_terms.clone())
+    assert torch.equal(out[False, 0.0][0], out[True, 0.0][0])
+    assert float((out[False, 0.01][0] - out[True, 0.01][0]).abs().max()) < 1e-6
+    assert float((out[False, 0.0][1] - out[True, 0.0][1]).abs().max()) <= 2e-6 * float(out[False, 0.0][1].abs().max())
