@@ -551,7 +551,7 @@ int launch_gaussian_backward(const BwdParams &p, const GeomWS &g, const BinWS &b
 //  k_gather_sums (grid x K, HBM-streaming, many waves in flight): a Gaussian's per-instance partial-gradient rows -- one
 //    contiguous run by emission slot, a wave's 64 Gaussians one contiguous block -- are streamed with coalesced loads and
 //    added in emission order; 48 bytes per Gaussian and view out (gsum).
-//  k_chain_view + k_chain_sum: below.
+//  k_chain_window + k_tau_sum: below.
 // one step of the keyed wave scan: lanes that receive a value through the DPP pattern CTRL (row mask ROWS) add it iff it comes from
 // the same owner; lanes the pattern does not reach see the key -1 and add nothing
 template <int CTRL, int ROWS>
@@ -667,125 +667,195 @@ __global__ __launch_bounds__(256) void k_gather_sums(int P, const int *__restric
   GSAJ_TRACE_END(gath)
 }
 
-// ---- the batched per-Gaussian backward: two launches --------------------------------------------------------------
-// (round 2 ran it as ONE kernel, 64 Gaussians x 4 waves, wave w taking views w, w + 4 with the SH backward inside: 213 VGPRs,
-// two waves per SIMD, a wave alive for 27 us of which 5 us issued instructions -- 70 us per cfg2 window.)
+// ---- the batched per-Gaussian backward ------------------------------------------------------------------------------
+// (round 2 ran it as 64 Gaussians x 4 waves, wave w taking views w, w + 4 one after the other with the SH backward inside:
+// 213 VGPRs, two waves per SIMD, a wave alive for 27 us of which 5 us issued instructions -- 70 us per cfg2 window.)
 //
-//  k_chain_view   grid (P / 256, K), lane = (view, Gaussian): the whole per-view chain on that view's sums (gaussian_chain_geom +
-//                 the view-direction term of the SH colour), no sum over views: K x P independent lanes fill the chip.  Writes the
-//                 view's per-Gaussian outputs (dL/dmean2D, ...), one row per (view, Gaussian) for the sums over views -- (dL/dopacity,
-//                 dL/dmean3D, dL/dcov3D, the colour gradient masked by the clamp flags, the SH basis weights of the view
-//                 direction) -- and a dL/dtau partial per wave.
-//  k_chain_sum    lane = (Gaussian, SH coefficient k), 16 lanes per Gaussian: adds the K views' rows IN VIEW ORDER (fixed order:
-//                 bit-reproducible) -- lane k < 10 component k of (dL/dopacity, dL/dmean3D, dL/dcov3D), every lane its
-//                 coefficient's dL/dSH[k][ch] = sum_v w_k(view) g_v[ch] -- all views' loads in flight together; lane 0 forms
-//                 dL/dscale, dL/drot ONCE from the summed dL/dcov3D (they are linear in it with view-independent coefficients).
-//                 Every summed output is written once (or added: GSAJ_BWD_ACCUMULATE).  Storage of at most one SH coefficient (SH-0
-//                 maps, precomputed colours): lane = Gaussian instead (16 lanes would share one 64-byte row per load).  K extra
-//                 workgroups, one per view, add that view's dL/dtau partials up in slot order (fp64): no tickets, no atomics.
-#define VROW_F4(MC) (4 + ((MC) > 1 ? ((MC) + 3) / 4 : 0))  // float4s per (view, Gaussian) row of GeomWS.vsum
+//  k_chain_window  one workgroup = 32 Gaussians x 8 views, lane = (view, Gaussian): every lane runs the whole per-view chain on
+//                  that view's sums (gaussian_chain_geom + the view-direction term of the SH colour) -- K x P independent lanes
+//                  fill the chip -- writes the view's own outputs (dL/dmean2D, ..., a dL/dtau partial per 32 Gaussians), and
+//                  leaves what the sums over views need in LDS: (dL/dopacity, dL/dmean3D, dL/dcov3D, the colour gradient
+//                  masked by the clamp flags, the SH basis weights of the view direction).  After a barrier the workgroup adds
+//                  the views IN VIEW ORDER (fixed order: bit-reproducible): thread t owns up to 8 of the 32 x (10 + 3 M)
+//                  elements -- component c of a Gaussian, or dL/dSH[k][ch] = sum_v w_k(view) g_v[ch] -- through every group
+//                  launch of 8 views (K > 8: further launches ADD to the outputs, in view order); dL/dscale, dL/drot are formed ONCE from the summed dL/dcov3D (they are linear in it with
+//                  view-independent coefficients); the block's outputs go out transposed through LDS, contiguous rows.
+//                  Nothing per (view, Gaussian) goes through memory except what the caller asked for.
+//  k_tau_sum       one workgroup per view adds that view's dL/dtau partials up in slot order (fp64).  No tickets: 31 256
+//                  workgroups (cfg5 window) drawing tickets from ONE word per view run at the ~88 returning atomics per us a
+//                  single address sustains (MI355X_MICROARCH.md, dequeue) -- 0.36 ms of a 1.2 ms kernel when tried.
+#define CW_G 32   // Gaussians per workgroup
+#define CW_V 8    // views per pass
 GSAJ_TRACE_DEFINE(gbb)
 
 template <int SHW>
-__global__ __launch_bounds__(256) void k_chain_view(BwdParams p, GeomWS g0, ImageWS im0, ViewStrides vs, float *__restrict__ pv_mean2D,
-                                                    float *__restrict__ pv_conic, float *__restrict__ pv_color,
-                                                    float *__restrict__ pv_depth, float *__restrict__ pv_tau) {
-  constexpr int MC = SHW / 3, ROW = VROW_F4(MC);
+__global__ __launch_bounds__(CW_G * CW_V, 4) void k_chain_window(BwdParams p, int v0, int K, GeomWS g0, ImageWS im0, ViewStrides vs,
+                                                              float *__restrict__ pv_mean2D, float *__restrict__ pv_conic,
+                                                              float *__restrict__ pv_color, float *__restrict__ pv_depth,
+                                                              float *__restrict__ pv_tau, int accumulate) {
+  constexpr int MC = SHW / 3;           // SH coefficients stored
+  constexpr int NV = 13 + MC;           // values a (view, Gaussian) lane leaves for the sums
+  constexpr int NE = 10 + SHW;          // summed outputs per Gaussian
+  constexpr int EPT = (NE * CW_G + CW_G * CW_V - 1) / (CW_G * CW_V);  // elements per thread
+  __shared__ float rowv[CW_V * NV * CW_G];  // [view lane][value][Gaussian]
+  __shared__ float outv[NE * CW_G];         // [element][Gaussian]: the sums, for the transposed store
   GSAJ_TRACE_BEGIN(gbb)
-  const int v = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
-  const GeomWS g = geom_view(g0, (size_t)v * vs.geom);
-  const uint32_t *counters = gsaj_shift(im0.counters, (size_t)v * vs.image);
-  const int idx = blockIdx.x * 256 + tid;
+  const int tid = threadIdx.x, gl = tid & (CW_G - 1), vl = tid / CW_G;
+  const int idx = blockIdx.x * CW_G + gl;
   const size_t ii = (size_t)(idx < p.P ? idx : 0);
-  // every input requested up front and unconditionally
-  const uint32_t aborted = counters[4];  // aborted async frame: contributes nothing
-  const int rad = p.radii[(size_t)v * p.P + ii];
-  const float4 s0 = g.gsum[3 * ii + 0], s1 = g.gsum[3 * ii + 1], s2 = g.gsum[3 * ii + 2];
+  // inputs that do not depend on the view: once
   const float3 mean = make_float3(p.means3D[3 * ii], p.means3D[3 * ii + 1], p.means3D[3 * ii + 2]);
   float c6[6];
 #pragma unroll
   for (int k = 0; k < 6; k++) c6[k] = p.cov3Ds[6 * ii + k];  // (view 0's copy: Sigma = R S^2 R^T does not depend on the view)
-  uint8_t cl[3] = {0, 0, 0};
-  if (SHW > 0) { cl[0] = g.clamped[3 * ii]; cl[1] = g.clamped[3 * ii + 1]; cl[2] = g.clamped[3 * ii + 2]; }
-  p.viewmatrix += 16 * v;
-  p.projmatrix += 16 * v;
-  const bool vis = idx < p.P && !aborted && rad > 0;
-  GaussianGrads o;
-  o.m2x = o.m2y = o.ca = o.cb = o.cc = o.op = o.dz = 0.f;
-  o.col = o.gm = make_float3(0.f, 0.f, 0.f);
+  const float *vm0 = p.viewmatrix, *pj0 = p.projmatrix;
+  float acc[EPT];
 #pragma unroll
-  for (int k = 0; k < 6; k++) o.cov[k] = 0.f;
-  float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  float w[MC > 0 ? MC : 1];  // SH basis weights of this view's direction
-#pragma unroll
-  for (int k = 0; k < MC; k++) w[k] = 0.f;
-  float3 gmask = make_float3(0.f, 0.f, 0.f);
-  if (vis) {
-    // the view-direction term first: its 3 M coefficient loads are consumed (and their registers free) before the geometric
-    // chain's own peak
-    float3 dmean = make_float3(0.f, 0.f, 0.f);
-    if (SHW > 0) {
-      const float *cam = p.campos + 3 * v;
-      constexpr int DEG_MAX = MC >= 16 ? 3 : (MC >= 9 ? 2 : (MC >= 4 ? 1 : 0));  // (the storage bounds the degree: dead bands compile away)
-      const float3 gcol = make_float3(s1.z, s1.w, s2.x);
-      dmean = sh_backward<1>(min(p.D, DEG_MAX), p.M, mean, make_float3(cam[0], cam[1], cam[2]), p.shs + ii * SHW, w, cl, gcol);
-      gmask = make_float3(cl[0] ? 0.f : gcol.x, cl[1] ? 0.f : gcol.y, cl[2] ? 0.f : gcol.z);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    gaussian_chain_geom(p, mean, c6, s0, s1, s2, o, tau);
-    if (SHW > 0) {
-      o.gm.x += dmean.x; o.gm.y += dmean.y; o.gm.z += dmean.z;
-      tau[0] -= dmean.x; tau[1] -= dmean.y; tau[2] -= dmean.z;
-    }
-  }
-  // ---- this view's dL/dtau: wave partials (the single-view kernel's butterfly), one slot per 64 Gaussians, added up in slot order
-  // (fp64) by k_chain_sum's extra workgroups.  No ticket here: 31 256 workgroups (cfg5 window) drawing tickets from ONE word per
-  // view, all resident ones on the same view, run at the ~88 returning atomics per us a single address sustains
-  // (MI355X_MICROARCH.md, dequeue): 0.36 ms of a 1.2 ms kernel.
+  for (int j = 0; j < EPT; j++) acc[j] = 0.f;
+  // views [v0, min(v0 + 8, K)) of the window.  (A loop over the groups of 8 views INSIDE the kernel cost 70 VGPRs: 201 instead of
+  // 132 -- the compiler kept view-independent values alive across it, whatever was hidden from it.)
   {
-    float t6[6];
+    const int v = v0 + vl;
+    GaussianGrads o;
+    o.m2x = o.m2y = o.ca = o.cb = o.cc = o.op = o.dz = 0.f;
+    o.col = o.gm = make_float3(0.f, 0.f, 0.f);
 #pragma unroll
-    for (int k = 0; k < 6; k++) {
-      float t = tau[k];
+    for (int k = 0; k < 6; k++) o.cov[k] = 0.f;
+    float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float w[MC > 0 ? MC : 1];  // SH basis weights of this view's direction
 #pragma unroll
-      for (int o2 = 32; o2 > 0; o2 >>= 1) t += __shfl_xor(t, o2);
-      t6[k] = t;
+    for (int k = 0; k < MC; k++) w[k] = 0.f;
+    float3 gmask = make_float3(0.f, 0.f, 0.f);
+    if (v < K) {
+      const GeomWS g = geom_view(g0, (size_t)v * vs.geom);
+      const size_t iv = ii;
+      const float3 mean_v = mean;
+      const float (&c6v)[6] = c6;
+      // every input of this (view, Gaussian) requested up front and unconditionally
+      const uint32_t aborted = gsaj_shift(im0.counters, (size_t)v * vs.image)[4];  // aborted async frame: contributes nothing
+      const int rad = p.radii[(size_t)v * p.P + ii];
+      const float4 s0 = g.gsum[3 * ii + 0], s1 = g.gsum[3 * ii + 1], s2 = g.gsum[3 * ii + 2];
+      uint8_t cl[3] = {0, 0, 0};
+      if (SHW > 0) { cl[0] = g.clamped[3 * ii]; cl[1] = g.clamped[3 * ii + 1]; cl[2] = g.clamped[3 * ii + 2]; }
+      p.viewmatrix = vm0 + 16 * v;
+      p.projmatrix = pj0 + 16 * v;
+      const bool vis = idx < p.P && !aborted && rad > 0;
+      if (vis) {
+        // the view-direction term first: its 3 M coefficient loads are consumed (and their registers free) before the geometric
+        // chain's own peak
+        float3 dmean = make_float3(0.f, 0.f, 0.f);
+        if (SHW > 0) {
+          const float *cam = p.campos + 3 * v;
+          constexpr int DEG_MAX = MC >= 16 ? 3 : (MC >= 9 ? 2 : (MC >= 4 ? 1 : 0));  // (the storage bounds the degree: dead bands compile away)
+          const float3 gcol = make_float3(s1.z, s1.w, s2.x);
+          dmean = sh_backward<1>(min(p.D, DEG_MAX), p.M, mean_v, make_float3(cam[0], cam[1], cam[2]), p.shs + iv * SHW, w, cl, gcol);
+          gmask = make_float3(cl[0] ? 0.f : gcol.x, cl[1] ? 0.f : gcol.y, cl[2] ? 0.f : gcol.z);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        gaussian_chain_geom(p, mean_v, c6v, s0, s1, s2, o, tau);
+        if (SHW > 0) {
+          o.gm.x += dmean.x; o.gm.y += dmean.y; o.gm.z += dmean.z;
+          tau[0] -= dmean.x; tau[1] -= dmean.y; tau[2] -= dmean.z;
+        }
+      }
+      // the view's own outputs
+      if (idx < p.P) {
+        const size_t row = (size_t)v * p.P + ii;
+        if (pv_mean2D) { pv_mean2D[3 * row] = o.m2x; pv_mean2D[3 * row + 1] = o.m2y; pv_mean2D[3 * row + 2] = 0.f; }
+        if (pv_conic) reinterpret_cast<float4 *>(pv_conic)[row] = make_float4(o.ca, o.cb, 0.f, o.cc);
+        if (pv_color) { pv_color[3 * row] = o.col.x; pv_color[3 * row + 1] = o.col.y; pv_color[3 * row + 2] = o.col.z; }
+        if (pv_depth) pv_depth[row] = o.dz;
+        if (pv_tau) {
+#pragma unroll
+          for (int k = 0; k < 6; k++) pv_tau[6 * row + k] = tau[k];
+        }
+      }
+      // this view's dL/dtau: partial over the 32 Gaussians (the lanes of one half-wave), one slot per (view, workgroup); k_tau_sum
+      // adds the slots up
+      float t6[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        float t = tau[k];
+#pragma unroll
+        for (int o2 = CW_G / 2; o2 > 0; o2 >>= 1) t += __shfl_xor(t, o2);
+        t6[k] = t;
+      }
+      if (gl == 0) {
+        float4 *tp = reinterpret_cast<float4 *>(g.tau_partials + (size_t)blockIdx.x * 8);
+        tp[0] = make_float4(t6[0], t6[1], t6[2], t6[3]);
+        tp[1] = make_float4(t6[4], t6[5], 0.f, 0.f);
+      }
     }
-    if (lane == 0 && blockIdx.x * 256 + (tid & ~63) < p.P) {
-      float4 *tp = reinterpret_cast<float4 *>(g.tau_partials + ((size_t)blockIdx.x * 4 + (tid >> 6)) * 8);
-      tp[0] = make_float4(t6[0], t6[1], t6[2], t6[3]);
-      tp[1] = make_float4(t6[4], t6[5], 0.f, 0.f);
+    // ---- what the sums over views need, through LDS ----
+    float *mine = rowv + vl * NV * CW_G + gl;
+    mine[0 * CW_G] = o.op; mine[1 * CW_G] = o.gm.x; mine[2 * CW_G] = o.gm.y; mine[3 * CW_G] = o.gm.z;
+#pragma unroll
+    for (int k = 0; k < 6; k++) mine[(4 + k) * CW_G] = o.cov[k];
+    mine[10 * CW_G] = gmask.x; mine[11 * CW_G] = gmask.y; mine[12 * CW_G] = gmask.z;
+#pragma unroll
+    for (int k = 0; k < MC; k++) mine[(13 + k) * CW_G] = w[k];
+    __syncthreads();
+    const int nv = min(CW_V, K - v0);
+#pragma unroll
+    for (int j = 0; j < EPT; j++) {
+      const int e = tid + j * (CW_G * CW_V);  // element e = c * 32 + Gaussian: this thread's Gaussian is always gl
+      const int c = e / CW_G;
+      if (c < NE) {
+        float sacc = acc[j];
+        if (c < 10) {
+#pragma unroll 2
+          for (int u = 0; u < nv; u++) sacc += rowv[u * NV * CW_G + c * CW_G + gl];
+        } else {
+          const int kk = (c - 10) / 3, ch = (c - 10) - 3 * kk;
+#pragma unroll 2
+          for (int u = 0; u < nv; u++) sacc += rowv[u * NV * CW_G + (13 + kk) * CW_G + gl] * rowv[u * NV * CW_G + (10 + ch) * CW_G + gl];
+        }
+        acc[j] = sacc;
+      }
     }
+    __syncthreads();
   }
-  if (idx < p.P) {
-    float4 *dst = g.vsum + (size_t)ROW * ii;
-    dst[0] = make_float4(o.op, o.gm.x, o.gm.y, o.gm.z);
-    dst[1] = make_float4(o.cov[0], o.cov[1], o.cov[2], o.cov[3]);
-    dst[2] = make_float4(o.cov[4], o.cov[5], gmask.x, gmask.y);
-    dst[3] = make_float4(gmask.z, 0.f, 0.f, 0.f);
-    if (MC > 1) {
+  // ---- the sums, transposed through LDS: [element][Gaussian] -> rows of the outputs ----
 #pragma unroll
-      for (int k = 0; k < (MC + 3) / 4; k++)
-        dst[4 + k] = make_float4(w[4 * k], 4 * k + 1 < MC ? w[4 * k + 1] : 0.f, 4 * k + 2 < MC ? w[4 * k + 2] : 0.f, 4 * k + 3 < MC ? w[4 * k + 3] : 0.f);
-    }
-    const size_t row = (size_t)v * p.P + ii;
-    if (pv_mean2D) { pv_mean2D[3 * row] = o.m2x; pv_mean2D[3 * row + 1] = o.m2y; pv_mean2D[3 * row + 2] = 0.f; }
-    if (pv_conic) reinterpret_cast<float4 *>(pv_conic)[row] = make_float4(o.ca, o.cb, 0.f, o.cc);
-    if (pv_color) { pv_color[3 * row] = o.col.x; pv_color[3 * row + 1] = o.col.y; pv_color[3 * row + 2] = o.col.z; }
-    if (pv_depth) pv_depth[row] = o.dz;
-    if (pv_tau) {
-#pragma unroll
-      for (int k = 0; k < 6; k++) pv_tau[6 * row + k] = tau[k];
-    }
+  for (int j = 0; j < EPT; j++) {
+    const int e = tid + j * (CW_G * CW_V);
+    if (e < NE * CW_G) outv[e] = acc[j];
   }
+  __syncthreads();
+  // accumulate: this call's sums are ADDED to what the buffers hold (a window processed in several calls, or keyframes of several
+  // windows accumulated on one rank before the optimiser step: callers add in a fixed order, so the result stays reproducible)
+#define OUT(dst, x) dst = accumulate ? dst + (x) : (x)
+  const int nG = min(CW_G, p.P - (int)blockIdx.x * CW_G);  // Gaussians of this workgroup
+  const size_t b0 = (size_t)blockIdx.x * CW_G;
+  for (int e = tid; e < nG; e += CW_G * CW_V) OUT(p.dL_dopacity[b0 + e], outv[0 * CW_G + e]);
+  for (int e = tid; e < 3 * nG; e += CW_G * CW_V) OUT(p.dL_dmean3D[3 * b0 + e], outv[(1 + e % 3) * CW_G + e / 3]);
+  for (int e = tid; e < 6 * nG; e += CW_G * CW_V) OUT(p.dL_dcov3D[6 * b0 + e], outv[(4 + e % 6) * CW_G + e / 6]);
+  if (SHW > 0 && p.dL_dsh) {  // (coefficients above the active degree have zero weights: their gradients come out zero)
+    for (int e = tid; e < SHW * nG; e += CW_G * CW_V) OUT(p.dL_dsh[(size_t)SHW * b0 + e], outv[(10 + e % SHW) * CW_G + e / SHW]);
+  }
+  if (p.scales && tid < nG) {  // dL/dscale, dL/drot from the summed dL/dcov3D (this call's part: both are linear in it)
+    const size_t i = b0 + tid;
+    float gcov[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) gcov[k] = outv[(4 + k) * CW_G + tid];
+    const float3 sc = make_float3(p.scales[3 * i], p.scales[3 * i + 1], p.scales[3 * i + 2]);
+    const float4 q = reinterpret_cast<const float4 *>(p.rotations)[i];
+    float3 dscale;
+    float4 drot;
+    cov3d_backward(gcov, sc, q, p.scale_modifier, dscale, drot);
+    OUT(p.dL_dscale[3 * i], dscale.x); OUT(p.dL_dscale[3 * i + 1], dscale.y); OUT(p.dL_dscale[3 * i + 2], dscale.z);
+    float4 *dr = reinterpret_cast<float4 *>(p.dL_drot) + i;
+    if (accumulate) { const float4 o4 = *dr; drot.x += o4.x; drot.y += o4.y; drot.z += o4.z; drot.w += o4.w; }
+    *dr = drot;
+  }
+#undef OUT
   GSAJ_TRACE_END(gbb)
 }
 
-GSAJ_TRACE_DEFINE(gbs)
-// workgroup `view` of the K extra ones: dL_dtau_sum[view] = sum of the view's per-wave partials in slot order, fp64
-__device__ __forceinline__ void chain_tau_sum(const BwdParams &p, const GeomWS &g0, ViewStrides vs, int view) {
+// workgroup `view`: dL_dtau_sum[view] = sum of the view's partials (one per 32 Gaussians) in slot order, fp64
+__global__ __launch_bounds__(256) void k_tau_sum(BwdParams p, GeomWS g0, ViewStrides vs) {
   __shared__ double red[256 * 6];
-  const int tid = threadIdx.x, nslot = (p.P + 63) / 64;
+  const int tid = threadIdx.x, view = blockIdx.x, nslot = (p.P + CW_G - 1) / CW_G;
   const float4 *tp = reinterpret_cast<const float4 *>(gsaj_shift(g0.tau_partials, (size_t)view * vs.geom));
   double a[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   for (int i = tid; i < nslot; i += 256) {
@@ -805,144 +875,12 @@ __device__ __forceinline__ void chain_tau_sum(const BwdParams &p, const GeomWS &
   if (tid < 6 && p.dL_dtau_sum) p.dL_dtau_sum[6 * view + tid] = (float)red[tid * 256];
 }
 
-#define CS_VB 8  // views whose loads are in flight together
-#define OUT(dst, x) dst = accumulate ? dst + (x) : (x)
-// accumulate: this call's sums are ADDED to what the buffers hold (a window processed in several calls, or keyframes of several
-// windows accumulated on one rank before the optimiser step: callers add in a fixed order, so the result stays reproducible)
-template <int SHW>
-__global__ __launch_bounds__(256) void k_chain_sum(BwdParams p, int K, int nblk, GeomWS g0, ViewStrides vs, int accumulate) {
-  constexpr int MC = SHW / 3, ROW = VROW_F4(MC);
-  if ((int)blockIdx.x >= nblk) {
-    chain_tau_sum(p, g0, vs, (int)blockIdx.x - nblk);
-    return;
-  }
-  GSAJ_TRACE_BEGIN(gbs)
-  const int tid = threadIdx.x, k = tid & 15;
-  const int idx = blockIdx.x * 16 + (tid >> 4);
-  const bool live = idx < p.P;
-  const size_t ii = (size_t)(live ? idx : 0);
-  // lane k: component k of (dL/dopacity, dL/dmean3D, dL/dcov3D) for k < 10, and dL/dSH[k][0..2] for k < MC
-  const int comp = k < 10 ? k : 0;
-  float csum = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f;
-  for (int v0 = 0; v0 < K; v0 += CS_VB) {
-    float cv[CS_VB], wv[CS_VB];
-    float4 ga[CS_VB], gb[CS_VB];
-#pragma unroll
-    for (int j = 0; j < CS_VB; j++) {  // every load of these views requested before the first use (rows of views past K: view K-1's, unused)
-      const int v = min(v0 + j, K - 1);
-      const float *row = reinterpret_cast<const float *>(gsaj_shift(g0.vsum, (size_t)v * vs.geom) + (size_t)ROW * ii);
-      cv[j] = row[comp];
-      ga[j] = reinterpret_cast<const float4 *>(row)[2];  // (cov4, cov5, g0, g1)
-      gb[j] = reinterpret_cast<const float4 *>(row)[3];  // (g2, -, -, -)
-      wv[j] = row[16 + (k < MC ? k : 0)];
-    }
-#pragma unroll
-    for (int j = 0; j < CS_VB; j++) {
-      if (v0 + j < K) {
-        csum += cv[j];
-        d0 += wv[j] * ga[j].z;
-        d1 += wv[j] * ga[j].w;
-        d2 += wv[j] * gb[j].x;
-      }
-    }
-  }
-  // ---- outputs, once per Gaussian ----
-  if (live) {
-    const size_t i = (size_t)idx;
-    if (k == 0) OUT(p.dL_dopacity[i], csum);
-    else if (k < 4) OUT(p.dL_dmean3D[3 * i + (k - 1)], csum);
-    else if (k < 10) OUT(p.dL_dcov3D[6 * i + (k - 4)], csum);
-    if (p.dL_dsh && k < MC) {
-      float *d = p.dL_dsh + i * SHW + 3 * k;
-      // (coefficients above the active degree have zero weights: their gradients come out zero)
-      OUT(d[0], d0); OUT(d[1], d1); OUT(d[2], d2);
-    }
-  }
-  if (p.scales) {  // dL/dscale, dL/drot from the summed dL/dcov3D (lanes 4..9 of the Gaussian's 16): lane 0
-    float gcov[6];
-#pragma unroll
-    for (int c = 0; c < 6; c++) gcov[c] = __shfl(csum, (threadIdx.x & 48) + 4 + c, 64);  // (this call's part: both are linear in it)
-    if (live && k == 0) {
-      const size_t i = (size_t)idx;
-      const float3 sc = make_float3(p.scales[3 * i], p.scales[3 * i + 1], p.scales[3 * i + 2]);
-      const float4 q = reinterpret_cast<const float4 *>(p.rotations)[i];
-      float3 dscale;
-      float4 drot;
-      cov3d_backward(gcov, sc, q, p.scale_modifier, dscale, drot);
-      OUT(p.dL_dscale[3 * i], dscale.x); OUT(p.dL_dscale[3 * i + 1], dscale.y); OUT(p.dL_dscale[3 * i + 2], dscale.z);
-      float4 *dr = reinterpret_cast<float4 *>(p.dL_drot) + i;
-      if (accumulate) { const float4 o4 = *dr; drot.x += o4.x; drot.y += o4.y; drot.z += o4.z; drot.w += o4.w; }
-      *dr = drot;
-    }
-  }
-  GSAJ_TRACE_END(gbs)
-}
-
-// at most one SH coefficient stored (SHW = 0: precomputed colours; 3: SH-0 maps): lane = Gaussian, the K rows of 64 bytes read whole
-template <int SHW>
-__global__ __launch_bounds__(256) void k_chain_sum1(BwdParams p, int K, int nblk, GeomWS g0, ViewStrides vs, int accumulate) {
-  static_assert(SHW == 0 || SHW == 3, "one coefficient at most");
-  constexpr int ROW = VROW_F4(SHW / 3);
-  if ((int)blockIdx.x >= nblk) {
-    chain_tau_sum(p, g0, vs, (int)blockIdx.x - nblk);
-    return;
-  }
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= p.P) return;
-  const size_t i = (size_t)idx;
-  float acc[13];
-#pragma unroll
-  for (int c = 0; c < 13; c++) acc[c] = 0.f;
-  for (int v0 = 0; v0 < K; v0 += 4) {
-    float4 r[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const float4 *row = gsaj_shift(g0.vsum, (size_t)min(v0 + j, K - 1) * vs.geom) + (size_t)ROW * i;
-      r[j][0] = row[0]; r[j][1] = row[1]; r[j][2] = row[2]; r[j][3] = row[3];
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      if (v0 + j < K) {
-        acc[0] += r[j][0].x; acc[1] += r[j][0].y; acc[2] += r[j][0].z; acc[3] += r[j][0].w;
-        acc[4] += r[j][1].x; acc[5] += r[j][1].y; acc[6] += r[j][1].z; acc[7] += r[j][1].w;
-        acc[8] += r[j][2].x; acc[9] += r[j][2].y; acc[10] += r[j][2].z; acc[11] += r[j][2].w; acc[12] += r[j][3].x;
-      }
-    }
-  }
-  OUT(p.dL_dopacity[i], acc[0]);
-  OUT(p.dL_dmean3D[3 * i], acc[1]); OUT(p.dL_dmean3D[3 * i + 1], acc[2]); OUT(p.dL_dmean3D[3 * i + 2], acc[3]);
-#pragma unroll
-  for (int c = 0; c < 6; c++) OUT(p.dL_dcov3D[6 * i + c], acc[4 + c]);
-  if (SHW > 0 && p.dL_dsh) {  // dL/dSH[0][ch] = C0 x the summed masked colour gradient
-    const float C0 = 0.28209479177387814f;
-    OUT(p.dL_dsh[3 * i], C0 * acc[10]); OUT(p.dL_dsh[3 * i + 1], C0 * acc[11]); OUT(p.dL_dsh[3 * i + 2], C0 * acc[12]);
-  }
-  if (p.scales) {
-    const float gcov[6] = {acc[4], acc[5], acc[6], acc[7], acc[8], acc[9]};
-    const float3 sc = make_float3(p.scales[3 * i], p.scales[3 * i + 1], p.scales[3 * i + 2]);
-    const float4 q = reinterpret_cast<const float4 *>(p.rotations)[i];
-    float3 dscale;
-    float4 drot;
-    cov3d_backward(gcov, sc, q, p.scale_modifier, dscale, drot);
-    OUT(p.dL_dscale[3 * i], dscale.x); OUT(p.dL_dscale[3 * i + 1], dscale.y); OUT(p.dL_dscale[3 * i + 2], dscale.z);
-    float4 *dr = reinterpret_cast<float4 *>(p.dL_drot) + i;
-    if (accumulate) { const float4 o4 = *dr; drot.x += o4.x; drot.y += o4.y; drot.z += o4.z; drot.w += o4.w; }
-    *dr = drot;
-  }
-}
-#undef OUT
-
 template <int SHW>
 static void launch_chain(const BwdParams &p, int K, const GeomWS &g, const ImageWS &im, ViewStrides vs, int accumulate, hipStream_t s) {
-  hipLaunchKernelGGL(k_chain_view<SHW>, dim3((p.P + 255) / 256, K), dim3(256), 0, s, p, g, im, vs, p.dL_dmean2D, p.dL_dconic, p.dL_dcolor,
-                     p.dL_ddepth, p.dL_dtau);
-  if constexpr (SHW <= 3) {
-    const int nblk = (p.P + 255) / 256;
-    hipLaunchKernelGGL(k_chain_sum1<SHW>, dim3(nblk + K), dim3(256), 0, s, p, K, nblk, g, vs, accumulate);
-  } else {
-    const int nblk = (p.P + 15) / 16;
-    hipLaunchKernelGGL(k_chain_sum<SHW>, dim3(nblk + K), dim3(256), 0, s, p, K, nblk, g, vs, accumulate);
-  }
+  for (int v0 = 0; v0 < K; v0 += CW_V)  // 8 views per launch; later launches add to the first one's sums (same stream: in view order)
+    hipLaunchKernelGGL(k_chain_window<SHW>, dim3((p.P + CW_G - 1) / CW_G), dim3(CW_G * CW_V), 0, s, p, v0, K, g, im, vs, p.dL_dmean2D,
+                       p.dL_dconic, p.dL_dcolor, p.dL_ddepth, p.dL_dtau, (accumulate || v0 > 0) ? 1 : 0);
+  hipLaunchKernelGGL(k_tau_sum, dim3(K), dim3(256), 0, s, p, g, vs);
 }
 
 int launch_gather_sums(int P, int K, const int *radii, const GeomWS &g, const BinWS &b, const ImageWS &im, ViewStrides vs, hipStream_t s) {

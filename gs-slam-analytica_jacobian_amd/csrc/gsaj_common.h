@@ -44,10 +44,7 @@ struct GeomWS {  // per-Gaussian state (reference: GeometryState, rasterizer_imp
                             //   (mean2D.x, mean2D.y, depth, first emission slot) (half2 a b, half2 c o, half2 r g, half2 b 0)
   uint2 *scat;              // [P] what the instance scatter reads: the tile rectangle (x0 | x1 << 16, y0 | y1 << 16); x1 == x0: no tile
   float4 *gsum;             // [P*3] batched backward: the Gaussian's 10 reverse-compositor sums (its instance rows added in
-                            //   emission order by k_gather_sums), read by k_chain_view
-  float4 *vsum;             // [P*8] batched backward: this view's row of every Gaussian (k_chain_view), summed over the views by
-                            //   k_chain_sum: (dL/dopacity, dL/dmean3D | dL/dcov3D 0..3 | 4, 5, masked colour gradient r, g | b, -, -, - |
-                            //   up to 16 SH basis weights); 4 + ceil(M / 4) float4s per row are used
+                            //   emission order by k_gather_sums), read by k_chain_window
 };
 
 static inline __host__ __device__ size_t geom_carve(char *base, size_t P, GeomWS *g) {
@@ -66,12 +63,11 @@ static inline __host__ __device__ size_t geom_carve(char *base, size_t P, GeomWS
   CARVE(point_offsets, uint32_t, P);
   CARVE(internal_radii, int, P);
   CARVE(block_sums, uint32_t, nblk);
-  CARVE(tau_partials, float, ((P + GB_BLOCK - 1) / GB_BLOCK + 1) * 8);
+  CARVE(tau_partials, float, ((P + 31) / 32 + 1) * 8);  // (one slot per 64 Gaussians single view, per 32 batched)
   CARVE(splat, float4, P * 3);
   CARVE(splat16, float4, P * 2);
   CARVE(scat, uint2, P);
   CARVE(gsum, float4, P * 3);
-  CARVE(vsum, float4, P * 8);
   return off;
 }
 
@@ -143,7 +139,7 @@ __device__ __forceinline__ GeomWS geom_view(GeomWS g, size_t off) {
   g.tiles_touched = gsaj_shift(g.tiles_touched, off); g.point_offsets = gsaj_shift(g.point_offsets, off);
   g.internal_radii = gsaj_shift(g.internal_radii, off); g.block_sums = gsaj_shift(g.block_sums, off);
   g.tau_partials = gsaj_shift(g.tau_partials, off); g.splat = gsaj_shift(g.splat, off); g.gsum = gsaj_shift(g.gsum, off);
-  g.splat16 = gsaj_shift(g.splat16, off); g.scat = gsaj_shift(g.scat, off); g.vsum = gsaj_shift(g.vsum, off);
+  g.splat16 = gsaj_shift(g.splat16, off); g.scat = gsaj_shift(g.scat, off);
   return g;
 }
 __device__ __forceinline__ ImageWS image_view(ImageWS m, size_t off) {

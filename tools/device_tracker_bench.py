@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""gsaj.tracking.DeviceTracker: ms per tracking iteration, eager C-ABI calls against the captured hipGraph, for a small frame
-(launch-bound) and the cfg2 frame (kernel-bound).  usage: device_tracker_bench.py [iterations=300]"""
+"""gsaj.tracking.DeviceTracker: ms per tracking iteration (best of 3 runs) -- eager C-ABI calls against the captured hipGraph, and the
+loss fused into the compositors against the separate loss kernel -- for a small frame (launch-bound) and the cfg2 frame
+(kernel-bound).  usage: device_tracker_bench.py [iterations=300]"""
 import json
 import math
 import os
@@ -31,16 +32,22 @@ def case(name, cam, sc, n):
     w2c = np.ascontiguousarray(cam["viewmatrix"].T).copy()
     w2c[:3, 3] += np.array([0.01, -0.008, 0.012], np.float32)
     out = {"workload": name, "P": P, "W": W, "H": H}
-    for use_graph in (False, True):
-        tr = DeviceTracker(P, W, H, M, dev, w2c, t(cam["projmatrix_raw"]), cam["tanfovx"], cam["tanfovy"], bg, alpha=0.9, use_graph=use_graph, **g)
+    # eager_ms / graph_ms: the loss fused into the compositors (the default); unfused_ms: forward -> gsaj_loss_seeds -> backward
+    for key, use_graph, fused in (("eager_ms", False, True), ("graph_ms", True, True), ("unfused_ms", False, False)):
+        tr = DeviceTracker(P, W, H, M, dev, w2c, t(cam["projmatrix_raw"]), cam["tanfovx"], cam["tanfovy"], bg, alpha=0.9, use_graph=use_graph,
+                           fused=fused, **g)
         tr.set_frame(gt.color, gt.depth[0])
         tr.iterate(20)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        tr.iterate(n)
-        torch.cuda.synchronize()
-        out["graph_ms" if use_graph else "eager_ms"] = round(1e3 * (time.perf_counter() - t0) / n, 4)
+        best = 1e9
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            tr.iterate(n)
+            torch.cuda.synchronize()
+            best = min(best, 1e3 * (time.perf_counter() - t0) / n)
+        out[key] = round(best, 4)
     out["speedup"] = round(out["eager_ms"] / out["graph_ms"], 2)
+    out["fused_over_unfused"] = round(out["unfused_ms"] / out["eager_ms"], 3)
     return out
 
 
