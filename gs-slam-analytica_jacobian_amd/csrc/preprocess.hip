@@ -105,6 +105,10 @@ __device__ __forceinline__ float3 sh_to_rgb(int deg, float3 pos, float3 campos, 
 
 GSAJ_TRACE_DEFINE(pre)
 
+// SH16: the SH colours come from 16 stored coefficients per channel (degree-3 maps): all 48 floats are requested up front, in
+// registers (108 VGPRs: four waves per SIMD).  Any other storage (SH-0 maps, precomputed colours) reads its few coefficients
+// where it needs them and runs at twice the occupancy -- this kernel is latency-bound.
+template <bool SH16>
 __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__restrict__ radii, int *__restrict__ n_touched,
                                                          GeomWS g, ImageWS im, ViewStrides vs) {
   __shared__ uint32_t scan[PRE_BLOCK / 64];
@@ -155,8 +159,8 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__re
       q_in = reinterpret_cast<const float4 *>(p.rotations)[idx];
     }
     const float opac_in = p.opacities[idx];
-    const bool sh_regs = !p.colors_precomp && p.M == 16;  // degree-3 storage: 48 floats = 12 x 16-byte loads
-    float shv[48];
+    constexpr bool sh_regs = SH16;  // degree-3 storage: 48 floats = 12 x 16-byte loads
+    float shv[SH16 ? 48 : 1];
     if (sh_regs) {
       const float4 *s4 = reinterpret_cast<const float4 *>(p.shs + (size_t)idx * 48);
 #pragma unroll
@@ -172,12 +176,14 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__re
       const float4 p_hom = xform4x4(p.projmatrix, p_orig);
       const float p_w = 1.0f / (p_hom.w + 0.0000001f);
       const float3 p_proj = make_float3(p_hom.x * p_w, p_hom.y * p_w, p_hom.z * p_w);
-      const float *c6;
+      float c6[6];  // (in registers: a pointer chosen between the caller's array and a local one put the local one in scratch memory)
       if (p.cov3D_precomp) {
-        c6 = p.cov3D_precomp + 6 * (size_t)idx;
+#pragma unroll
+        for (int k = 0; k < 6; k++) c6[k] = p.cov3D_precomp[6 * (size_t)idx + k];
       } else {
         cov3d_from_scale_rot(sc_in, p.scale_modifier, q_in, c6s);
-        c6 = c6s;
+#pragma unroll
+        for (int k = 0; k < 6; k++) c6[k] = c6s[k];
       }
       const float3 cov = cov2d_forward(p_orig, p.focal_x, p.focal_y, p.tanfovx, p.tanfovy, c6, p.viewmatrix);
       const float det = cov.x * cov.z - cov.y * cov.y;
@@ -195,7 +201,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__re
         if (area != 0) {
           if (!p.colors_precomp) {
             const float3 cam = make_float3(p.campos[0], p.campos[1], p.campos[2]);
-            if (sh_regs) rgb = sh_to_rgb(p.D, p_orig, cam, shv, cl);
+            if constexpr (sh_regs) rgb = sh_to_rgb(p.D, p_orig, cam, shv, cl);
             else rgb = sh_to_rgb(p.D, p_orig, cam, p.shs + (size_t)idx * p.M * 3, cl);
           }
           rect_pack = (uint32_t)x0 | ((uint32_t)y0 << 10) | ((uint32_t)(x1 - x0) << 20);
@@ -865,7 +871,14 @@ int launch_preprocess(const FwdParams &p, int *radii, int *n_touched, const Geom
     GsajProfScope ps(ST_PREPROCESS, s);
     const int tiles = p.grid_x * p.grid_y;
     const size_t lds = tiles <= LDS_TILES_MAX ? sizeof(uint32_t) * (size_t)tiles : 0;
-    hipLaunchKernelGGL(k_preprocess, dim3(nblk, views), dim3(PRE_BLOCK), lds, s, p, radii, n_touched, g, im, vs);
+#ifndef GSAJ_PRE_NO_SHREGS
+    if (!p.colors_precomp && p.M == 16)
+#else
+    if (false)
+#endif
+      hipLaunchKernelGGL(k_preprocess<true>, dim3(nblk, views), dim3(PRE_BLOCK), lds, s, p, radii, n_touched, g, im, vs);
+    else
+      hipLaunchKernelGGL(k_preprocess<false>, dim3(nblk, views), dim3(PRE_BLOCK), lds, s, p, radii, n_touched, g, im, vs);
     hipLaunchKernelGGL(k_frame_scan, dim3(1, views), dim3(PRE_BLOCK), lds, s, nblk, tiles, p.capacity, g, im, vs);
   }
   GSAJ_HIP_CHECK(hipGetLastError());
