@@ -197,6 +197,7 @@ struct FwdParams {
   int grid_x, grid_y;
   int capacity;  // > 0: async forward, binning arena holds this many instances
   int sort_cap;  // async forward: longest tile list the caller sized the LDS sort for (0: SORT_CAP)
+  int bpw;       // k_preprocess: blocks of 256 Gaussians per workgroup (set by launch_preprocess)
   int views;     // gridDim.y of the per-view kernels (1: single view); view v reads viewmatrix + 16 v, projmatrix + 16 v,
                  // campos + 3 v and writes radii + P v, n_touched + P v
 };

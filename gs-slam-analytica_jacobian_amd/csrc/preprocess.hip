@@ -108,7 +108,8 @@ GSAJ_TRACE_DEFINE(pre)
 // SH16: the SH colours come from 16 stored coefficients per channel (degree-3 maps): all 48 floats are requested up front, in
 // registers (108 VGPRs: four waves per SIMD).  Any other storage (SH-0 maps, precomputed colours) reads its few coefficients
 // where it needs them and runs at twice the occupancy -- this kernel is latency-bound.
-template <bool SH16>
+// MULTI: the workgroup loops over p.bpw blocks (the loop costs ~20 VGPRs: only launches that need it get this instantiation).
+template <bool SH16, bool MULTI>
 __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__restrict__ radii, int *__restrict__ n_touched,
                                                          GeomWS g, ImageWS im, ViewStrides vs) {
   __shared__ uint32_t scan[PRE_BLOCK / 64];
@@ -131,13 +132,22 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__re
 #define TRP(i)
 #endif
   const int tid = threadIdx.x;
-  const int idx = blockIdx.x * PRE_BLOCK + tid;
   const int tiles = p.grid_x * p.grid_y;
   const bool use_lds = tiles <= LDS_TILES_MAX;
   if (use_lds) {
     for (int t = tid; t < tiles; t += PRE_BLOCK) hist[t] = 0u;
     __syncthreads();
   }
+  // A workgroup takes p.bpw consecutive blocks of 256 Gaussians, one after the other, and flushes its tile histogram ONCE: a
+  // 256-Gaussian block of a 10^6-Gaussian 1280x720 frame leaves ~2800 instances in ~2000 of the 3600 tiles -- LDS aggregation
+  // saves nothing there and the flush was 62 M global atomics per window (launch_preprocess picks bpw > 1 only for such launches).
+  // Everything per-Gaussian stays per 256-block (block scan, block_sums: the emission slots are counted inside a block).
+  const int nblk_all = (p.P + PRE_BLOCK - 1) / PRE_BLOCK;
+#pragma clang loop unroll(disable)
+  for (int it = 0; it < (MULTI ? p.bpw : 1); it++) {
+  const int blk = MULTI ? (int)blockIdx.x * p.bpw + it : (int)blockIdx.x;
+  if (blk >= nblk_all) break;
+  const int idx = blk * PRE_BLOCK + tid;
   uint32_t touched = 0;
   uint32_t rect_x = 0, rect_y = 0;  // x0 | x1 << 16, y0 | y1 << 16 (GeomWS.scat)
   float depth = 0.f;
@@ -251,12 +261,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__re
     }
     if (lane == 63) scan[tid >> 6] = incl;
   }
-  __syncthreads();  // (also: every thread's LDS histogram atomics are done)
-  if (use_lds)
-    for (int t = tid; t < tiles; t += PRE_BLOCK) {
-      const uint32_t c = hist[t];
-      if (c) atomicAdd(&im.tile_count[t], c);
-    }
+  __syncthreads();
   uint32_t block_total = 0;
 #pragma unroll
   for (int w = 0; w < PRE_BLOCK / 64; w++) {
@@ -271,7 +276,14 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(FwdParams p, int *__re
     reinterpret_cast<float *>(g.splat)[12 * (size_t)idx + 3] = __uint_as_float(first);
     g.scat[idx] = make_uint2(rect_x, rect_y);
   }
-  if (tid == 0) g.block_sums[blockIdx.x] = block_total;  // block totals -> exclusive offsets: k_frame_scan
+  if (tid == 0) g.block_sums[blk] = block_total;  // block totals -> exclusive offsets: k_frame_scan
+  __syncthreads();  // (scan[] is written again by the next block; after the last one: every thread's LDS histogram atomics are done)
+  }
+  if (use_lds)
+    for (int t = tid; t < tiles; t += PRE_BLOCK) {
+      const uint32_t c = hist[t];
+      if (c) atomicAdd(&im.tile_count[t], c);
+    }
   TRP(1)
   GSAJ_TRACE_END(pre)
 #ifdef GSAJ_BLOCK_TRACE
@@ -858,10 +870,15 @@ __global__ __launch_bounds__(256) void k_zero_frame_state(uint32_t *__restrict__
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) c[i] = 0u;
 }
 
-int launch_preprocess(const FwdParams &p, int *radii, int *n_touched, const GeomWS &g, const ImageWS &im, ViewStrides vs,
+int launch_preprocess(const FwdParams &p0, int *radii, int *n_touched, const GeomWS &g, const ImageWS &im, ViewStrides vs,
                       hipStream_t s) {
+  FwdParams p = p0;
   const int nblk = (p.P + PRE_BLOCK - 1) / PRE_BLOCK;
   const int views = p.views > 0 ? p.views : 1;
+  // blocks of 256 Gaussians per workgroup: 1 unless the launch has far more workgroups than the chip holds (k_preprocess)
+  p.bpw = 1;
+  while (p.bpw < 8 && (long long)nblk * views / (2 * p.bpw) >= 4096) p.bpw *= 2;
+  const int nwg = (nblk + p.bpw - 1) / p.bpw;
   {
     const size_t words = im.zero_bytes / sizeof(uint32_t);
     hipLaunchKernelGGL(k_zero_frame_state, dim3((unsigned)((words + 1023) / 1024), views), dim3(256), 0, s, im.counters, words,
@@ -876,9 +893,11 @@ int launch_preprocess(const FwdParams &p, int *radii, int *n_touched, const Geom
 #else
     if (false)
 #endif
-      hipLaunchKernelGGL(k_preprocess<true>, dim3(nblk, views), dim3(PRE_BLOCK), lds, s, p, radii, n_touched, g, im, vs);
+      if (p.bpw > 1) hipLaunchKernelGGL((k_preprocess<true, true>), dim3(nwg, views), dim3(PRE_BLOCK), lds, s, p, radii, n_touched, g, im, vs);
+      else hipLaunchKernelGGL((k_preprocess<true, false>), dim3(nwg, views), dim3(PRE_BLOCK), lds, s, p, radii, n_touched, g, im, vs);
     else
-      hipLaunchKernelGGL(k_preprocess<false>, dim3(nblk, views), dim3(PRE_BLOCK), lds, s, p, radii, n_touched, g, im, vs);
+      if (p.bpw > 1) hipLaunchKernelGGL((k_preprocess<false, true>), dim3(nwg, views), dim3(PRE_BLOCK), lds, s, p, radii, n_touched, g, im, vs);
+      else hipLaunchKernelGGL((k_preprocess<false, false>), dim3(nwg, views), dim3(PRE_BLOCK), lds, s, p, radii, n_touched, g, im, vs);
     hipLaunchKernelGGL(k_frame_scan, dim3(1, views), dim3(PRE_BLOCK), lds, s, nblk, tiles, p.capacity, g, im, vs);
   }
   GSAJ_HIP_CHECK(hipGetLastError());
