@@ -630,79 +630,156 @@ __device__ __forceinline__ uint32_t lane_xor(uint32_t x, int lane) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
   }
 }
-// one bitonic stage of stride J < 64 on the two keys a lane holds (indices base + lane and base + 64 + lane)
-template <int J>
-__device__ __forceinline__ void sort_stage(uint64_t &A, uint64_t &B, int lane, bool ascA, bool ascB) {
-  const uint64_t PA = ((uint64_t)lane_xor<J>((uint32_t)(A >> 32), lane) << 32) | lane_xor<J>((uint32_t)A, lane);
-  const uint64_t PB = ((uint64_t)lane_xor<J>((uint32_t)(B >> 32), lane) << 32) | lane_xor<J>((uint32_t)B, lane);
-  const bool lower = (lane & J) == 0;  // this lane holds the lower-indexed key of the pair
-  A = ((A < PA) == (lower == ascA)) ? A : PA;  // lower & ascending (or upper & descending) keeps the smaller key
-  B = ((B < PB) == (lower == ascB)) ? B : PB;
+// value of lane (l ^ MASK) for MASK = 2^j - 1: the mirror inside groups of 2, 4, 8, 16, 32, 64 lanes (DPP quad_perm /
+// row_half_mirror / row_mirror, + the half-row / half-wave swaps above)
+template <int MASK>
+__device__ __forceinline__ uint32_t lane_mirror(uint32_t x, int lane) {
+  if (MASK == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);         // quad_perm [1,0,3,2]
+  else if (MASK == 3) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x1B, 0xF, 0xF, false);    // quad_perm [3,2,1,0]
+  else if (MASK == 7) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, false);   // row_half_mirror
+  else if (MASK == 15) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xF, 0xF, false);  // row_mirror
+  else if (MASK == 31) return lane_xor<16>(lane_mirror<15>(x, lane), lane);
+  else return lane_xor<32>(lane_mirror<31>(x, lane), lane);
+}
+template <int MASK>
+__device__ __forceinline__ uint64_t key_mirror(uint64_t k, int lane) {
+  return ((uint64_t)lane_mirror<MASK>((uint32_t)(k >> 32), lane) << 32) | lane_mirror<MASK>((uint32_t)k, lane);
 }
 
-// strides J, J/2, ..., 1 of one bitonic merge (J = 64: the in-lane comparator between a lane's two keys first)
+// The network is the ALL-ASCENDING form of the bitonic sort: the merge of two sorted runs of length K/2 opens with a "flip"
+// (element i against element K - 1 - i of the block) and continues with the half-cleaners of stride K/4 ... 1, every comparator
+// putting the smaller key at the lower index.  Keys past the end of a list are +inf and an all-ascending comparator never
+// moves +inf down: whole chunks, merges and comparators that would touch only padding are skipped, so a list of 315 keys costs
+// what 384 keys cost, not 512 (the alternating-direction form of rounds 1-2 had to sort the padding too).
+//
+// one half-cleaner stage of stride J < 64 on the two keys a lane holds (indices base + lane and base + 64 + lane)
 template <int J>
-__device__ __forceinline__ void merge_strides(uint64_t &A, uint64_t &B, int lane, bool ascA, bool ascB) {
+__device__ __forceinline__ void sort_stage(uint64_t &A, uint64_t &B, int lane) {
+  const uint64_t PA = ((uint64_t)lane_xor<J>((uint32_t)(A >> 32), lane) << 32) | lane_xor<J>((uint32_t)A, lane);
+  const uint64_t PB = ((uint64_t)lane_xor<J>((uint32_t)(B >> 32), lane) << 32) | lane_xor<J>((uint32_t)B, lane);
+  const bool lower = (lane & J) == 0;  // this lane holds the lower-indexed key of the pair: it keeps the smaller key
+  A = ((A < PA) == lower) ? A : PA;
+  B = ((B < PB) == lower) ? B : PB;
+}
+// half-cleaners of stride J, J/2, ..., 1 (J = 64: the in-lane comparator between a lane's two keys first)
+template <int J>
+__device__ __forceinline__ void merge_strides(uint64_t &A, uint64_t &B, int lane) {
   if constexpr (J == 64) {
     const uint64_t lo = A < B ? A : B, hi = A < B ? B : A;
-    A = ascA ? lo : hi;  // (stride 64 belongs to merges of size >= 128: ascA == ascB)
-    B = ascA ? hi : lo;
+    A = lo;
+    B = hi;
   } else {
-    sort_stage<J>(A, B, lane, ascA, ascB);
+    sort_stage<J>(A, B, lane);
   }
-  if constexpr (J > 1) merge_strides<J / 2>(A, B, lane, ascA, ascB);
+  if constexpr (J > 1) merge_strides<J / 2>(A, B, lane);
+}
+// the flip of a merge of size K <= 128 inside the chunk, then its half-cleaners
+template <int K>
+__device__ __forceinline__ void local_merge(uint64_t &A, uint64_t &B, int lane) {
+  if constexpr (K == 128) {  // index l (key A of lane l) against index 127 - l (key B of lane 63 - l)
+    const uint64_t PA = key_mirror<63>(B, lane), PB = key_mirror<63>(A, lane);
+    A = A < PA ? A : PA;
+    B = B < PB ? PB : B;
+    merge_strides<32>(A, B, lane);
+  } else {  // inside A and inside B: lane l against lane l ^ (K - 1)
+    const uint64_t PA = key_mirror<K - 1>(A, lane), PB = key_mirror<K - 1>(B, lane);
+    const bool lower = (lane & (K / 2)) == 0;
+    A = ((A < PA) == lower) ? A : PA;
+    B = ((B < PB) == lower) ? B : PB;
+    if constexpr (K >= 4) merge_strides<K / 4>(A, B, lane);
+  }
 }
 // the merges of size K, 2K, ..., 128 (all inside the chunk), stopping at the padded list length m
 template <int K>
-__device__ __forceinline__ void local_merges(uint64_t &A, uint64_t &B, int lane, int ia, int ib, int m) {
+__device__ __forceinline__ void local_merges(uint64_t &A, uint64_t &B, int lane, int m) {
   if (K > m) return;
-  merge_strides<K / 2>(A, B, lane, (ia & K) == 0, (ib & K) == 0);
-  if constexpr (K < 128) local_merges<2 * K>(A, B, lane, ia, ib, m);
+  local_merge<K>(A, B, lane);
+  if constexpr (K < 128) local_merges<2 * K>(A, B, lane, m);
 }
 
-// The strides >= 128 of the merge of size k (through LDS, workgroup barriers), then the seven chunk-local strides in registers.
-// asc_all: every comparator ascending (the final merge of a bitonic sequence of length k = m).
-__device__ __forceinline__ void lds_merge_level(uint64_t *keys, int m, int k, bool asc_all, int tid) {
+// Sort of keys[0, n) in LDS, ascending; keys[n, ceil(n / 128) * 128) must hold +inf (~0); n >= 1.  Barrier before (the caller's
+// stores to `keys`), barrier after.  Comparators with stride <= 64 pair keys inside one aligned 128-key chunk, and a wave holds
+// a chunk in REGISTERS (lane l: keys l and l + 64): stride 64 is in-lane, the mirrors and strides 32 / 16 use
+// v_permlane32_swap / v_permlane16_swap, the rest DPP -- an LDS round trip per stage was the latency of this kernel.  So the
+// chunk sorts (merges up to 128) never touch LDS, and a merge of size k >= 256 goes through LDS only for its flip and its
+// strides >= 128 (workgroup barriers), followed by the seven chunk-local stages in registers again.
+__device__ __forceinline__ void lds_bitonic_sort(uint64_t *keys, int n, int tid) {
   const int lane = tid & 63, wave = tid >> 6;
-  for (int j = k >> 1; j >= 128; j >>= 1) {
-    for (int i = tid; i < (m >> 1); i += 256) {
+  const int nch = (n + 127) >> 7, nup = nch << 7;  // chunks with at least one key; everything at or past nup is padding nobody reads
+  int m = 2;
+  while (m < n) m <<= 1;
+  for (int chunk = wave; chunk < nch; chunk += 4) {
+    const int ia = chunk * 128 + lane, ib = ia + 64;
+    uint64_t A = keys[ia], B = keys[ib];
+    local_merges<2>(A, B, lane, m);
+    keys[ia] = A;
+    keys[ib] = B;
+  }
+  __syncthreads();
+  for (int k = 256, hs = 7; (k >> 1) < nup; k <<= 1, hs++) {
+    // blocks of k keys whose upper half holds a key: [base, base + k) with base + k / 2 < nup.  The others are sorted already.
+    const int half = k >> 1;  // = 1 << hs
+    // flip: base + off against base + k - 1 - off
+    for (int i = tid; i < (nup >> 1) + half; i += 256) {  // (i enumerates (block, off) over every block that starts below nup)
+      const int blk = i >> hs, off = i & (half - 1);
+      const int l = (blk << (hs + 1)) + off, r = (blk << (hs + 1)) + k - 1 - off;
+      if (r < nup) {
+        const uint64_t a = keys[l], b = keys[r];
+        if (a > b) {
+          keys[l] = b;
+          keys[r] = a;
+        }
+      }
+    }
+    __syncthreads();
+    for (int j = k >> 2; j >= 128; j >>= 1) {  // half-cleaners through LDS
+      for (int i = tid; i < (nup >> 1); i += 256) {
+        const int l = ((i & ~(j - 1)) << 1) | (i & (j - 1)), r = l + j;
+        if (r < nup && ((l & ~(k - 1)) + half) < nup) {
+          const uint64_t a = keys[l], b = keys[r];
+          if (a > b) {
+            keys[l] = b;
+            keys[r] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    for (int chunk = wave; chunk < nch; chunk += 4) {
+      if (((chunk * 128) & ~(k - 1)) + half >= nup) continue;  // (its block's upper half is padding)
+      const int ia = chunk * 128 + lane, ib = ia + 64;
+      uint64_t A = keys[ia], B = keys[ib];
+      merge_strides<64>(A, B, lane);
+      keys[ia] = A;
+      keys[ib] = B;
+    }
+    __syncthreads();
+  }
+}
+
+// keys[0, T) holds a BITONIC sequence (ascending, +inf, descending: sort_long_list's merge step), T a power of two >= 128:
+// its half-cleaners of stride T/2 ... 1 sort it.
+__device__ __forceinline__ void lds_bitonic_merge(uint64_t *keys, int T, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int j = T >> 1; j >= 128; j >>= 1) {
+    for (int i = tid; i < (T >> 1); i += 256) {
       const int l = ((i & ~(j - 1)) << 1) | (i & (j - 1)), r = l + j;
       const uint64_t a = keys[l], b = keys[r];
-      if ((a > b) == (asc_all || (l & k) == 0)) {
+      if (a > b) {
         keys[l] = b;
         keys[r] = a;
       }
     }
     __syncthreads();
   }
-  for (int chunk = wave; chunk * 128 < m; chunk += 4) {
+  for (int chunk = wave; chunk * 128 < T; chunk += 4) {
     const int ia = chunk * 128 + lane, ib = ia + 64;
     uint64_t A = keys[ia], B = keys[ib];
-    const bool asc = asc_all || (ia & k) == 0;  // k >= 256: one direction for the whole chunk
-    merge_strides<64>(A, B, lane, asc, asc);
+    merge_strides<64>(A, B, lane);
     keys[ia] = A;
     keys[ib] = B;
   }
   __syncthreads();
-}
-
-// Bitonic sort of keys[0, m) in LDS, m a power of two (>= 2), ascending; the caller's stores to `keys` need no barrier before
-// the call only if each thread reads what it wrote -- so: barrier before.  Comparators with stride <= 64 pair keys inside one
-// aligned 128-key chunk, and a wave holds a chunk in REGISTERS (lane l: keys l and l + 64): stride 64 is in-lane, strides
-// 32 / 16 use v_permlane32_swap / v_permlane16_swap, strides 8..1 DPP -- an LDS round trip per stage was the latency of this
-// kernel.  So the first 28 stages (k = 2..128: every chunk sorted on its own) never touch LDS, and for k >= 256 only the
-// strides >= 128 do (with workgroup barriers), followed by the seven chunk-local stages in registers again.
-__device__ __forceinline__ void lds_bitonic_sort(uint64_t *keys, int m, int tid) {
-  const int lane = tid & 63, wave = tid >> 6;
-  for (int chunk = wave; chunk * 128 < m; chunk += 4) {
-    const int ia = chunk * 128 + lane, ib = ia + 64;
-    uint64_t A = ia < m ? keys[ia] : ~0ull, B = ib < m ? keys[ib] : ~0ull;
-    local_merges<2>(A, B, lane, ia, ib, m);
-    if (ia < m) keys[ia] = A;
-    if (ib < m) keys[ib] = B;
-  }
-  __syncthreads();
-  for (int k = 256; k <= m; k <<= 1) lds_merge_level(keys, m, k, false, tid);
 }
 
 // A tile list longer than the LDS holds (n > T keys; the reference's global radix sort takes any length,
@@ -762,7 +839,7 @@ __device__ const uint64_t *sort_long_list(uint64_t *lds, int T, const uint32_t *
           const int b0 = d0 - a0, cA = a1 - a0, cB = (d1 - a1) - b0;
           for (int i = tid; i < T; i += 256) lds[i] = i < cA ? A[a0 + i] : (i >= T - cB ? B[b0 + (T - 1 - i)] : ~0ull);
           __syncthreads();
-          lds_merge_level(lds, T, T, true, tid);
+          lds_bitonic_merge(lds, T, tid);
           for (int i = tid; i < cA + cB; i += 256) D[d0 + i] = lds[i];
           __syncthreads();
         }
@@ -826,7 +903,8 @@ __global__ __launch_bounds__(256) void k_tile_sort(ImageWS im, const float *__re
     if (pass == 1 && 2 * m <= cap) return;  // pass 2's
     if (pass == 2 && m > cap) return;       // pass 1's (here cap = half of pass 1's)
     // the tile's ids as scattered (point_list, sorted in place below) + their depths gathered from the 4-byte depth array (L2)
-    for (int i = tid; i < m; i += 256) {
+    const int nup = ((n + 127) >> 7) << 7;  // (+inf up to the end of the last 128-key chunk: lds_bitonic_sort)
+    for (int i = tid; i < nup; i += 256) {
       uint64_t key = ~0ull;
       if (i < n) {
         const uint32_t id = point_list[beg + i];
@@ -838,7 +916,7 @@ __global__ __launch_bounds__(256) void k_tile_sort(ImageWS im, const float *__re
 #ifdef GSAJ_BLOCK_TRACE
     tr_b = wall_clock64();
 #endif
-    lds_bitonic_sort(keys, m, tid);
+    lds_bitonic_sort(keys, n, tid);
   }
 #ifdef GSAJ_BLOCK_TRACE
   tr_c = wall_clock64();
