@@ -5,7 +5,7 @@ import json
 import sys
 
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/parity_errors.jsonl"
-dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r02_parity_errors.json"
+dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r03_parity_errors.json"
 worst, n = {}, 0
 for line in open(src):
     r = json.loads(line)
