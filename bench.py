@@ -331,8 +331,8 @@ def run(a):
                 "k_scatter_instances": hbm("k_scatter_instances", "scatter_instances", scat_bytes),
                 "k_tile_sort": hbm("k_tile_sort", "tile_sort_records", sort_bytes),
                 "k_gather_sums": hbm("k_gather_sums", "gather_sums", gather_bytes),
-                "k_chain_view+k_chain_sum": dict(hbm("k_chain_view", "gaussian_bwd", chain_bytes),
-                                                 note="two launches timed as one stage: the per-(view, Gaussian) chain and the sum over views")},
+                "k_chain_window+k_tau_sum": dict(hbm("k_chain_window", "gaussian_bwd", chain_bytes),
+                                                 note="timed as one stage: the per-(view, Gaussian) chain with the sum over views (one launch per 8 views) and the fp64 dL/dtau tree")},
             "stage_ms_per_step": {k: v / a.steps for k, v in prof.ms.items() if prof.launches[k]},
             "non_compositor_ms_per_step": sum(v for k, v in prof.ms.items() if prof.launches[k] and k not in ("render_fwd", "render_bwd")) / a.steps,
             "single_stream": None if not n_single else {"ms_per_frame": 1e3 * elapsed_single / n_single, "value_rank0": inter_1 * n_single / elapsed_single,

@@ -63,11 +63,13 @@ size_t gsaj_binning_workspace_bytes(int R);
 
 /* ---- per-call flags of the forward entry points (the library keeps NO process-wide mode: two threads may render
  * frames of different formats on different streams at the same time) ---------------------------------------------
- * GSAJ_FWD_RECORDS_FP16: the sorted instance records of THIS frame are 32-byte records with conic, opacity and colour
+ * GSAJ_FWD_RECORDS_FP16: the compositors of THIS frame read 32-byte per-Gaussian splat rows with conic, opacity and colour
  * rounded to half once (positions, depth, every accumulation and every gradient stay fp32) -- BASELINE config 5,
  * "fp16 splat with fp32 Jacobian accumulation"; integer outputs (radii, lists, ranges) are unchanged, images /
- * gradients move by ~1e-3 relative.  Default: 48-byte fp32 records.  The format is latched in the frame's image
- * workspace, where the matching backward reads it. */
+ * gradients move by ~1e-3 relative.  Default: 48-byte fp32 rows.  The format is latched in the frame's image
+ * workspace, where the matching backward reads it.  (The name is historical: up to round 2 the rows were per-instance
+ * records; since the compositors gather per-Gaussian rows the mode saves 16 of 48 bytes per GAUSSIAN, which no longer
+ * buys time on MI355X -- see DESIGN.md section 5.) */
 #define GSAJ_FWD_RECORDS_FP16 1
 
 /* ---- forward, two-phase form --------------------------------------------------------- */
@@ -85,11 +87,12 @@ int gsaj_forward_preprocess(int P, int D, int M, int W, int H,
 /* Blocking: number of (Gaussian, tile) instances produced by phase A. */
 int gsaj_forward_num_rendered(int W, int H, const void *image_ws, void *stream, int *num_rendered /*host*/,
                               int *max_tile_list /*host, may be NULL: longest per-tile list*/);
-/* Phase B: instance scatter into per-tile lists, per-tile (depth, id) sort in LDS (global radix
- * sort of (tile, depth) keys if a tile list exceeds the LDS capacity), per-instance record gather,
- * front-to-back compositing.  out_color [3,H,W], out_depth [1,H,W], out_opacity [1,H,W],
- * n_touched [P] int32.  R must be the value phase A produced. */
-int gsaj_forward_render(int P, int R, int max_tile_list /* from phase A; < 0 forces the global-sort path */, int W, int H,
+/* Phase B: instance scatter into per-tile id lists, per-tile (depth, id) sort in LDS (a list longer than the LDS capacity
+ * is sorted in LDS-sized chunks and merged in place by the same workgroup: no list length is refused), front-to-back
+ * compositing straight from the sorted id list (the compositor gathers the per-Gaussian 48-byte rows of phase A).
+ * out_color [3,H,W], out_depth [1,H,W], out_opacity [1,H,W], n_touched [P] int32.  R must be the value phase A produced. */
+int gsaj_forward_render(int P, int R, int max_tile_list /* from phase A: sizes the LDS sort; < 0 forces the chunk + merge path
+                                                           (128-key chunks) for every list longer than 128 -- for tests */, int W, int H,
                         const float *bg /*dev [3]*/,
                         const float *colors_precomp /*dev [P,3] or NULL*/, const int *radii /*dev [P] or NULL*/,
                         void *geom_ws, void *binning_ws, size_t binning_ws_bytes, void *image_ws,
@@ -112,14 +115,14 @@ int gsaj_rasterize_forward(int P, int D, int M, const float *bg, int W, int H,
 /* ---- forward without any host synchronisation (tracking / mapping inner loops) -----------------
  * The caller provides a binning workspace sized for `capacity` instances
  * (gsaj_binning_workspace_bytes(capacity)) and passes the SAME capacity as `R` to
- * gsaj_rasterize_backward.  If the frame needs more instances than that, or a tile list longer than
- * the in-LDS sort handles, the frame is aborted on the device (outputs undefined) and
+ * gsaj_rasterize_backward.  If the frame needs more instances than that, the frame is aborted on the
+ * device (every later kernel of the frame returns at once: outputs are the previous frame's) and
  * gsaj_forward_num_rendered -- which may be called at any later time -- returns
  * GSAJ_ERR_WORKSPACE_TOO_SMALL together with the R to size the arena for; the caller then repeats
- * the frame (with a larger arena, or through the synchronising entry points, which also have the
- * global-sort fallback).  tile_list_capacity (0 = the maximum, 16384): the longest tile list the frame may
- * contain; the per-tile LDS sort is given exactly that much shared memory, so scenes with short lists keep
- * more workgroups resident.  A frame with a longer list is aborted like one that overflows the arena. */
+ * the frame with a larger arena.  tile_list_capacity (0 = the maximum, 16384): the tile-list length the
+ * per-tile LDS sort is sized for (rounded up to a power of two >= 128); the sort is given exactly that much
+ * shared memory, so scenes with short lists keep more workgroups resident.  It is a performance hint only:
+ * a longer list is sorted in chunks of that size and merged (slower, same result) -- never an abort. */
 int gsaj_rasterize_forward_async(int P, int D, int M, const float *bg, int W, int H,
                                  const float *means3D, const float *shs, const float *colors_precomp,
                                  const float *opacities, const float *scales, float scale_modifier,
@@ -191,8 +194,8 @@ int gsaj_rasterize_backward(int P, int D, int M, int R, const float *bg, int W, 
  * gsaj_image_workspace_bytes(W, H) and gsaj_binning_workspace_bytes(capacity) bytes, 256-byte aligned, the image workspaces
  * zeroed once by the caller; view v's block can be handed to gsaj_forward_num_rendered / gsaj_forward_aborted_count /
  * gsaj_debug_export on its own.  Like gsaj_rasterize_forward_async there is NO host synchronisation: `capacity` instances
- * per view, a view that needs more (or a longer tile list than tile_list_capacity) is aborted on the device, contributes
- * nothing to the sums, and is reported by gsaj_forward_num_rendered(view block).
+ * per view, a view that needs more is aborted on the device, contributes nothing to the sums, and is reported by
+ * gsaj_forward_num_rendered(view block); tile_list_capacity as in gsaj_rasterize_forward_async (a hint, never an abort).
  *
  * Backward outputs.  Summed over the views: dL_dopacity [P], dL_dmean3D [P,3], dL_dcov3D [P,6], dL_dsh [P,M,3], dL_dscale
  * [P,3], dL_drot [P,4].  Per view (each may be NULL): dL_dmean2D [K,P,3] (what densification reads as
@@ -249,7 +252,9 @@ int gsaj_debug_export_view_sums(int P, const void *geom_ws, float *sums /*dev [P
  * Between gsaj_profile_begin and gsaj_profile_end every kernel launch of the library is
  * bracketed by HIP events on the stream it is launched on.  gsaj_profile_end synchronises,
  * and returns per stage the summed duration in ms and the number of launches.
- * Stage order: GSAJ_STAGE_NAMES. */
+ * Stage order: GSAJ_STAGE_NAMES.  (scan_blocks, emit_keys, sort, ranges_records and tau_finalize belong to kernels that no
+ * longer exist; the slots are kept so that the indices of the others do not move, and report 0 launches.  tile_sort_records
+ * is k_tile_sort -- it sorts ids now, there are no per-instance records.) */
 #define GSAJ_NUM_STAGES 14
 #define GSAJ_STAGE_NAMES "preprocess,scan_blocks,emit_keys,sort,ranges_records,render_fwd,render_bwd,gaussian_bwd,tau_finalize,dense_bwd,dense_reduce,scatter_instances,tile_sort_records,gather_sums"
 int gsaj_profile_begin(int max_records);

@@ -130,9 +130,9 @@ def test_bench_window_through_the_batched_path_three_layers():
     through BatchContext (gsaj_rasterize_forward_batch / _backward_batch) -- held to the same three layers as the single-view
     path (helpers.assert_grads_close), per view: (A) the reverse compositor's 10 sums per Gaussian (k_render_bwd +
     k_gather_sums; exported per view) inside the oracle's error model, (B) the per-Gaussian chain on the device's own sums
-    against the chain carried in fp64 (per-view: the dL/dtau rows and their sum, k_chain_view), (C) end to end; integers
+    against the chain carried in fp64 (per-view: the dL/dtau rows and their sum, k_chain_window), (C) end to end; integers
     bit-exact, images and n_contrib / n_touched different only where a threshold decision lies within rounding.  Then the
-    window's SUMS over the 8 keyframes (dL/dmean3D, dL/dcov3D via scale / rotation, dL/dSH, dL/dopacity: k_chain_sum)
+    window's SUMS over the 8 keyframes (dL/dmean3D, dL/dcov3D via scale / rotation, dL/dSH, dL/dopacity: k_chain_window)
     against the sum of the per-view fp64 chains on the device's sums, every row bounded by the SUM of the per-view bounds of
     layer (B); dL/dopacity by the sum of the per-view bounds of layer (A)."""
     import torch
