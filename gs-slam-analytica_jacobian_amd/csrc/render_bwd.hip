@@ -43,6 +43,12 @@
 #define ACC_STRIDE (BWD_ROUND + 1)  // acc[wave][partial][entry]: the end-of-round merge reads consecutive words
 
 GSAJ_TRACE_DEFINE(bwd)
+GSAJ_TRACE_DEFINE(bwdph)  // per-wave phase times of the rounds (trace build; tools/batch_trace.py)
+#ifdef GSAJ_BLOCK_TRACE
+#define BWD_PH(i) { const unsigned long long now_ = wall_clock64(); ph_[i] += (unsigned)(now_ - pht_); pht_ = now_; }
+#else
+#define BWD_PH(i)
+#endif
 
 // LOSS: the loss-fused form (gsaj_rasterize_backward_loss): a pixel's seeds dL/dC, dL/dD are derived in the
 // prologue from the images the forward wrote and the ground truth (loss_terms.h: the stand-alone loss kernel's arithmetic, same
@@ -139,7 +145,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     if (hi > range.x && lo0 + (uint32_t)tid < hi) id_nxt = point_list[lo0 + tid];
   }
 
+#ifdef GSAJ_BLOCK_TRACE
+  unsigned ph_[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  unsigned long long pht_ = wall_clock64();
+#endif
   while (hi > range.x) {
+    BWD_PH(6)
     const uint32_t lo = (hi - range.x > BWD_ROUND) ? hi - BWD_ROUND : range.x;
     const int n = (int)(hi - lo);
     if (tid < n) {
@@ -172,7 +183,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
       float4 *z = reinterpret_cast<float4 *>(acc);
       for (int i = tid; i < 4 * ACC_C * ACC_STRIDE / 4; i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    BWD_PH(0)
     __syncthreads();
+    BWD_PH(1)
 
     const uint32_t first_idx = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lo - range.x));  // list index (0-based) of rec[0]; workgroup-uniform -> scalar
     if (wmax > first_idx) {
@@ -297,7 +310,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         if (nslot > 0) flush();
       }
     }
+    BWD_PH(2)
     __syncthreads();
+    BWD_PH(3)
     if (tid < n) {
       float t[ACC_C];
 #pragma unroll
@@ -314,9 +329,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
       dst[2] = s2;
       reached[emit] = 1;
     }
+    BWD_PH(4)
     __syncthreads();
+    BWD_PH(5)
     hi = lo;
   }
+#ifdef GSAJ_BLOCK_TRACE
+  {
+    const unsigned tw_ = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if ((threadIdx.x & 63) == 0 && tw_ < GSAJ_TRACE_MAX) {
+      g_trace_bwdph[4 * tw_ + 0] = ((unsigned long long)ph_[0] << 32) | ph_[1];
+      g_trace_bwdph[4 * tw_ + 1] = ((unsigned long long)ph_[2] << 32) | ph_[3];
+      g_trace_bwdph[4 * tw_ + 2] = ((unsigned long long)ph_[4] << 32) | ph_[5];
+      g_trace_bwdph[4 * tw_ + 3] = ph_[6];
+    }
+  }
+#endif
   GSAJ_TRACE_END(bwd)
 }
 

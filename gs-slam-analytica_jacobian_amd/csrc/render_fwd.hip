@@ -8,9 +8,11 @@
 // entries: lane l takes entry l -- its Gaussian id from point_list (coalesced; requested TWO chunks ahead) and that
 // Gaussian's 48-byte row gathered from GeomWS.splat (requested ONE chunk ahead; the rows of a frame live in L2) -- a
 // lane-parallel test of the entry against the quadrant box (wave_reduce.h), and the survivors PACKED in list order into
-// the wave's LDS area with the conic pre-scaled for v_exp_f32.  The entry loop is straight-line, two entries per step, the next step's
-// records requested from LDS before this step's arithmetic; a pixel that skips an entry runs the same arithmetic with
-// weight 0 instead of branching.  Early-outs are wave-level ballots (a quadrant whose 64 pixels have all saturated
+// the wave's LDS area with the conic pre-scaled for v_exp_f32 -- PAIR-INTERLEAVED (x_A x_B y_A y_B | kx_A kx_B ky_A ky_B | ...), so that
+// ds_read_b128 delivers the register pairs the packed fp32 instructions take: the compiler paired entries before, but paid 31
+// v_mov shuffles per four entries for it (120 -> 96 VALU instructions per four entries, 231 -> 219 us per cfg2 window).  The
+// entry loop is straight-line, two pairs per step, the next half-step's pair requested from LDS before this one's arithmetic;
+// a pixel that skips an entry runs the same arithmetic with weight 0 instead of branching.  Early-outs are wave-level ballots (a quadrant whose 64 pixels have all saturated
 // stops), not the reference's block-wide votes.  n_touched: lane l counts packed entry l, only while some pixel of the
 // quadrant still has T > 0.5, and ONE atomic wave-instruction per 64 entries flushes it (the reference issues one
 // atomic per pixel per entry, forward.cu:512-514).  Tiles are taken longest list first (ImageWS.tile_order).
@@ -20,6 +22,8 @@
 
 #define FWD_CHUNK 64  // records staged per wave per trip
 #define FWD_PAD 8     // inert records after the packed ones: the pipelined entry loop reads up to 7 slots past the last
+#define FWD_PAIR_F4 6  // float4 per staged PAIR of entries (pair-interleaved layout, see composite2)
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 // Workgroup shape.  The four quadrant waves of a tile never talk to each other (no barrier, private LDS areas), so each can be
 // its own 64-thread workgroup: a 256-thread workgroup holds its CU slots until its SLOWEST wave is done, and the quadrants of a
@@ -61,7 +65,7 @@ __global__ __launch_bounds__(GSAJ_FWD_THREADS) __attribute__((amdgpu_waves_per_e
   // Each wave (one 8x8 quadrant) walks the tile list on its own: private 64-record staging area, no
   // workgroup barrier anywhere, so a quadrant never waits for a slower neighbour.  The four waves of a
   // tile gather the same rows; the repeats are served by L1/L2.
-  __shared__ float4 rec_all[FWD_WAVES * (FWD_CHUNK + FWD_PAD) * REC_F4];
+  __shared__ float4 rec_all[FWD_WAVES * ((FWD_CHUNK + FWD_PAD) / 2) * FWD_PAIR_F4];
   if (counters[4]) return;  // aborted async frame
   GSAJ_TRACE_BEGIN(fwd)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(GSAJ_FWD_THREADS) __attribute__((amdgpu_waves_per_e
 #else
   const int wave = tid >> 6;
   const int tile = (int)min(im.tile_order[blockIdx.x], (uint32_t)(tiles - 1));
-  float4 *rec = rec_all + wave * (FWD_CHUNK + FWD_PAD) * REC_F4;
+  float4 *rec = rec_all + wave * ((FWD_CHUNK + FWD_PAD) / 2) * FWD_PAIR_F4;
 #endif
   const int ty = tile / gx, tx = tile - ty * gx;
   const int px = tx * TILE + (wave & 1) * 8 + (lane & 7);
@@ -89,30 +93,58 @@ __global__ __launch_bounds__(GSAJ_FWD_THREADS) __attribute__((amdgpu_waves_per_e
   const uint2 range = ranges[tile];
 
   bool done = !inside;
-  float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f, Dp = 0.f;
+  float T = 1.0f;
   uint32_t last = 0;
   bool counting = true;  // wave-uniform: some pixel of the quadrant still has T > 0.5 (only those can "touch")
 
-  // One packed list entry for this lane's pixel.  g = (mean x, mean y, depth), k = conic pre-scaled so that
-  // k.x dx^2 + k.y dx dy + k.z dy^2 = log2(e) * power, k.w = opacity, c = (rgb, 1-based list position).
-  // A pixel that skips the entry runs the same arithmetic with alpha = 0: T, C, D come out unchanged.
-  auto composite = [&](const float4 g, const float4 k, const float4 c, float &test_T) -> bool {
-    const float dx = g.x - pxf, dy = g.y - pyf;
-    const float p2 = gsaj_power2(dx, dy, k.x, k.y, k.z);
-    const float alpha0 = fminf(0.99f, k.w * __builtin_amdgcn_exp2f(p2));
-    bool ok = !done && p2 <= 0.0f && alpha0 >= (1.0f / 255.0f);
-    test_T = T - alpha0 * T;
-    const bool sat = ok && test_T < 0.0001f;  // this pixel is saturated: stop before this entry
-    done = done || sat;
-    ok = ok && !sat;
-    const float w = ok ? alpha0 * T : 0.f;
-    Cr += c.x * w;
-    Cg += c.y * w;
-    Cb += c.z * w;
-    Dp += g.z * w;
-    T = ok ? test_T : T;
-    last = ok ? __float_as_uint(c.w) : last;
-    return ok;
+  // TWO packed list entries (A, B: consecutive in list order) for this lane's pixel, stored pair-interleaved in LDS so that the
+  // arithmetic both entries share -- dx, dy, the power, opacity x G -- runs as packed fp32 instructions (v_pk_add / v_pk_mul /
+  // v_pk_fma_f32) on register pairs exactly as ds_read_b128 delivers them (no v_mov shuffles):
+  //   p0 = (x_A, x_B, y_A, y_B)   p1 = (kx_A, kx_B, ky_A, ky_B)   p2 = (kz_A, kz_B, o_A, o_B)   cA / cB = (r, g, b, depth)
+  //   pos = (1-based list positions of A, B)
+  // with k the conic pre-scaled so that kx dx^2 + ky dx dy + kz dy^2 = log2(e) * power.  The sequential part (T, saturation) is
+  // scalar, A before B; colour + depth accumulate as two packed pairs.  A pixel that skips an entry runs the same arithmetic
+  // with weight 0: T, C, D come out unchanged.  Every operation is the one gsaj_power2 / the reverse compositor use (IEEE
+  // mul / fma, packed or not): both passes decide on identical bits.
+  v2f Crg = {0.f, 0.f}, Cbd = {0.f, 0.f};
+  const v2f px2 = {pxf, pxf}, py2 = {pyf, pyf};
+  auto composite2 = [&](const float4 p0, const float4 p1, const float4 p2, const float4 cA, const float4 cB, const float2 pos,
+                        float &tA, float &tB, bool &okA, bool &okB) {
+    const v2f dx = v2f{p0.x, p0.y} - px2, dy = v2f{p0.z, p0.w} - py2;
+    const v2f t = v2f{p1.z, p1.w} * dy;
+    const v2f u = v2f{p2.x, p2.y} * dy;
+    const v2f pw = __builtin_elementwise_fma(dx, __builtin_elementwise_fma(v2f{p1.x, p1.y}, dx, t), u * dy);
+    const v2f oe = v2f{p2.z, p2.w} * v2f{__builtin_amdgcn_exp2f(pw.x), __builtin_amdgcn_exp2f(pw.y)};
+    {
+      const float alpha0 = fminf(0.99f, oe.x);
+      bool ok = !done && pw.x <= 0.0f && alpha0 >= (1.0f / 255.0f);
+      tA = __builtin_fmaf(-alpha0, T, T);
+      const bool sat = ok && tA < 0.0001f;  // this pixel is saturated: stop before this entry
+      done = done || sat;
+      ok = ok && !sat;
+      const float w = ok ? alpha0 * T : 0.f;
+      const v2f w2 = {w, w};
+      Crg = __builtin_elementwise_fma(v2f{cA.x, cA.y}, w2, Crg);
+      Cbd = __builtin_elementwise_fma(v2f{cA.z, cA.w}, w2, Cbd);
+      T = ok ? tA : T;
+      last = ok ? __float_as_uint(pos.x) : last;
+      okA = ok;
+    }
+    {
+      const float alpha0 = fminf(0.99f, oe.y);
+      bool ok = !done && pw.y <= 0.0f && alpha0 >= (1.0f / 255.0f);
+      tB = __builtin_fmaf(-alpha0, T, T);
+      const bool sat = ok && tB < 0.0001f;
+      done = done || sat;
+      ok = ok && !sat;
+      const float w = ok ? alpha0 * T : 0.f;
+      const v2f w2 = {w, w};
+      Crg = __builtin_elementwise_fma(v2f{cB.x, cB.y}, w2, Crg);
+      Cbd = __builtin_elementwise_fma(v2f{cB.z, cB.w}, w2, Cbd);
+      T = ok ? tB : T;
+      last = ok ? __float_as_uint(pos.y) : last;
+      okB = ok;
+    }
   };
 
   if (__builtin_amdgcn_ballot_w64(!done) != 0ull && range.x < range.y) {
@@ -127,6 +159,15 @@ __global__ __launch_bounds__(GSAJ_FWD_THREADS) __attribute__((amdgpu_waves_per_e
     auto fetch_row = [&](uint32_t base) {  // (of the chunk whose ids fetch_id requested last)
       id_cur = id_nxt;
       if (base + (uint32_t)lane < range.y) gsaj_load_row(splat, splat16, id_nxt, rec16, q0, q1, q2);
+    };
+    float *recf = reinterpret_cast<float *>(rec);
+    // packed slot s -> pair s / 2, half s % 2 of the pair-interleaved layout (FWD_PAIR_F4 float4 per pair)
+    auto put = [&](int s, float x, float y, float kx, float ky, float kz, float o, float4 c, uint32_t pos, uint32_t id) {
+      const int h = s & 1, pb = (s >> 1) * FWD_PAIR_F4;
+      float *f = recf + pb * 4 + h;
+      f[0] = x; f[2] = y; f[4] = kx; f[6] = ky; f[8] = kz; f[10] = o;
+      rec[pb + 3 + h] = c;
+      f[20] = __uint_as_float(pos); f[22] = __uint_as_float(id);
     };
     fetch_id(range.x);
     fetch_row(range.x);
@@ -144,11 +185,9 @@ __global__ __launch_bounds__(GSAJ_FWD_THREADS) __attribute__((amdgpu_waves_per_e
       if (rel) {
         const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(todo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)todo, 0u));
         const float3 k = gsaj_prescale_conic(q1.x, q1.y, q1.z);
-        rec[slot * REC_F4 + 0] = make_float4(q0.x, q0.y, q0.z, __uint_as_float(id_here));
-        rec[slot * REC_F4 + 1] = make_float4(k.x, k.y, k.z, q1.w);
-        rec[slot * REC_F4 + 2] = make_float4(q2.x, q2.y, q2.z, __uint_as_float(base - range.x + (uint32_t)lane + 1u));
+        put(slot, q0.x, q0.y, k.x, k.y, k.z, q1.w, make_float4(q2.x, q2.y, q2.z, q0.z), base - range.x + (uint32_t)lane + 1u, id_here);
       }
-      if (lane < FWD_PAD * REC_F4) rec[nrel * REC_F4 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);  // inert sentinels (opacity 0)
+      if (lane < FWD_PAD) put(nrel + lane, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, make_float4(0.f, 0.f, 0.f, 0.f), 0u, 0u);  // inert sentinels (opacity 0)
       fetch_row(base + FWD_CHUNK);
       fetch_id(base + 2 * FWD_CHUNK);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -159,16 +198,19 @@ __global__ __launch_bounds__(GSAJ_FWD_THREADS) __attribute__((amdgpu_waves_per_e
       // every lane takes its byte after the loop
       uint32_t cnt4 = 0u;
       bool wave_done = false;
-      // two entries per step; the records of the next step are requested from LDS before this step's arithmetic
-      float4 a0 = rec[0], a1 = rec[1], a2 = rec[2], b0 = rec[3], b1 = rec[4], b2 = rec[5];
+      // two pairs per step; the pair of the next half-step is requested from LDS before this half-step's arithmetic
+      const float2 *rec2 = reinterpret_cast<const float2 *>(rec);
+      float4 a0 = rec[0], a1 = rec[1], a2 = rec[2], a3 = rec[3], a4 = rec[4];
+      float2 a5 = rec2[10];
       for (int i = 0; i < nrel; i += 4) {
-        const float4 c0 = rec[i * REC_F4 + 6], c1 = rec[i * REC_F4 + 7], c2 = rec[i * REC_F4 + 8];
-        const float4 d0 = rec[i * REC_F4 + 9], d1 = rec[i * REC_F4 + 10], d2 = rec[i * REC_F4 + 11];
+        const int pb = (i >> 1) * FWD_PAIR_F4;
+        const float4 c0 = rec[pb + 6], c1 = rec[pb + 7], c2 = rec[pb + 8], c3 = rec[pb + 9], c4 = rec[pb + 10];
+        const float2 c5 = rec2[(pb + 11) * 2];
         uint32_t pack = 0u;  // (scalar)
         {
           float tA, tB;
-          const bool okA = composite(a0, a1, a2, tA);
-          const bool okB = composite(b0, b1, b2, tB);
+          bool okA, okB;
+          composite2(a0, a1, a2, a3, a4, a5, tA, tB, okA, okB);
           if (counting) {
             const uint32_t nA = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(okA && tA > 0.5f));
             const uint32_t nB = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(okB && tB > 0.5f));
@@ -176,12 +218,12 @@ __global__ __launch_bounds__(GSAJ_FWD_THREADS) __attribute__((amdgpu_waves_per_e
             counting = __builtin_amdgcn_ballot_w64(T > 0.5f) != 0ull;
           }
         }
-        a0 = rec[i * REC_F4 + 12], a1 = rec[i * REC_F4 + 13], a2 = rec[i * REC_F4 + 14];
-        b0 = rec[i * REC_F4 + 15], b1 = rec[i * REC_F4 + 16], b2 = rec[i * REC_F4 + 17];
+        a0 = rec[pb + 12], a1 = rec[pb + 13], a2 = rec[pb + 14], a3 = rec[pb + 15], a4 = rec[pb + 16];
+        a5 = rec2[(pb + 17) * 2];
         {
           float tC, tD;
-          const bool okC = composite(c0, c1, c2, tC);
-          const bool okD = composite(d0, d1, d2, tD);
+          bool okC, okD;
+          composite2(c0, c1, c2, c3, c4, c5, tC, tD, okC, okD);
           if (counting) {
             const uint32_t nC = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(okC && tC > 0.5f));
             const uint32_t nD = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(okD && tD > 0.5f));
@@ -197,7 +239,7 @@ __global__ __launch_bounds__(GSAJ_FWD_THREADS) __attribute__((amdgpu_waves_per_e
       }
       const int cnt = (int)((cnt4 >> (8 * (lane & 3))) & 0xffu);
       if (lane < nrel && cnt > 0) {
-        const uint32_t id = __float_as_uint(rec[lane * REC_F4 + 0].w);
+        const uint32_t id = __float_as_uint(recf[(lane >> 1) * FWD_PAIR_F4 * 4 + 22 + (lane & 1)]);
         atomicAdd(&n_touched[id], cnt);
       }
       __builtin_amdgcn_wave_barrier();
@@ -205,6 +247,7 @@ __global__ __launch_bounds__(GSAJ_FWD_THREADS) __attribute__((amdgpu_waves_per_e
     }
   }
 
+  const float Cr = Crg.x, Cg = Crg.y, Cb = Cbd.x, Dp = Cbd.y;
   if (inside) {
     const size_t pid = (size_t)py * W + px;
     const size_t HW = (size_t)H * W;

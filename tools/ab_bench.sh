@@ -8,8 +8,8 @@ for n in "$@"; do
   GSAJ_LIB_PATH=$lib timeout -k 10 120 python bench.py --no-cpu-baseline --steps 40 $BENCH_ARGS > gpurun_out/ab_$n.json 2> gpurun_out/ab_$n.err || { echo "$n FAILED"; tail -3 gpurun_out/ab_$n.err; exit 1; }
   python - "$n" <<'PY'
 import json, sys
-d = json.load(open("gpurun_out/ab_%s.json" % sys.argv[1]))
+d = json.loads(open("gpurun_out/ab_%s.json" % sys.argv[1]).read().strip().splitlines()[-1])
 st = d["stage_ms_per_step"]
-print("%-10s step %.4f single %.4f | " % (sys.argv[1], d["ms_per_step"], d["single_stream"]["ms_per_frame"]) + " ".join("%s %.0f" % (k[:12], v * 1e3) for k, v in st.items()))
+print("%-10s step %.4f single %.4f | " % (sys.argv[1], d["ms_per_step"], (d["single_stream"] or {"ms_per_frame": 0.0})["ms_per_frame"]) + " ".join("%s %.0f" % (k[:12], v * 1e3) for k, v in st.items()))
 PY
 done; done

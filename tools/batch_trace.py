@@ -65,6 +65,26 @@ def main():
             labels = {"pre": "per-Gaussian work / histogram flush + block scan / - / -",
                       "scat": "zero LDS + loads / LDS count / reserve (returning atomics) / stores"}[name]
             print("      phases (us, mean): %s = %s" % (labels, " / ".join("%.1f" % (x.astype(np.int64).mean() * 0.01) for x in ph)))
+        if name == "bwd":
+            bwd_phases(lib, n)
+
+
+def bwd_phases(lib, n):
+    """Where a reverse-compositor wave spends its rounds (trace build): mean us per wave, wave 0 of a workgroup (it stages and
+    merges) and the others."""
+    fn = getattr(lib, "gsaj_trace_read_bwdph", None)
+    if fn is None:
+        return
+    fn.argtypes, fn.restype = [ctypes.c_void_p, ctypes.c_int], ctypes.c_int
+    n = min(n, 65536)
+    raw = np.zeros((n, 4), np.uint64)
+    assert fn(raw.ctypes.data, n) == 0
+    lo32 = np.uint64(0xffffffff)
+    ph = np.stack([raw[:, 0] >> np.uint64(32), raw[:, 0] & lo32, raw[:, 1] >> np.uint64(32), raw[:, 1] & lo32, raw[:, 2] >> np.uint64(32),
+                   raw[:, 2] & lo32, raw[:, 3] & lo32], 1).astype(np.int64) * 0.01
+    names = "stage (row gather, zero acc) / barrier 1 / phases 1+2 / barrier 2 / merge + row stores / barrier 3 / loop head"
+    for label, sel in (("wave 0", np.arange(n) % 4 == 0), ("waves 1-3", np.arange(n) % 4 != 0)):
+        print("      bwd %s, us per wave (mean): %s = %s  (sum %.1f)" % (label, names, " / ".join("%.1f" % x for x in ph[sel].mean(0)), ph[sel].sum(1).mean()))
 
 
 if __name__ == "__main__":
