@@ -334,6 +334,17 @@ __device__ __forceinline__ void gsaj_load_row(const float4 *__restrict__ splat, 
 // bypasses this CU's L1 and this XCD's L2 (sc0 sc1), with its wait inside the statement (the compiler takes an asm's outputs
 // for ready when the statement ends).  Coherent loads cost ~100 ns each and do not overlap (tools/chain_trace.py), so the
 // "last workgroup sums the partials" tails use as few and as wide ones as they can.
+// 16 bytes from a 4-byte-aligned address (global_load_dwordx4 needs no more): one load instruction where the C++ type system would
+// want four.
+// The pointer is stated to be GLOBAL memory (a flat load is counted by the LDS counter too, so every LDS wait would wait for it).
+__device__ __forceinline__ float4 gsaj_load_f4_unaligned(const void *src) {
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+  const f4u v = *reinterpret_cast<const __attribute__((address_space(1))) f4u *>((unsigned long long)src);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint32_t gsaj_load_u32_global(const uint32_t *src) {
+  return *reinterpret_cast<const __attribute__((address_space(1))) uint32_t *>((unsigned long long)src);
+}
 __device__ __forceinline__ uint4 gsaj_coherent_load_x4(const void *src) {
   uint4 v;
   asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(src) : "memory");

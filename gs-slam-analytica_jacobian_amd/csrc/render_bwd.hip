@@ -80,6 +80,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
   __shared__ float2 wu_all[4 * SLOTS * WU_STRIDE];     // [wave][slot][pixel] (w, u)
   __shared__ float4 seed_all[4 * 64];                  // [wave][pixel] (dL/dC rgb, dL/dD)
   __shared__ uint32_t wave_max[4];
+  __shared__ uint32_t blk_first[BWD_ROUND];
   if (counters[4]) return;  // aborted async frame
   GSAJ_TRACE_BEGIN(bwd)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -139,10 +140,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
   // stay as the tile sort left them (opaque scenes leave most of a long list unreached: neither their ids nor their rows
   // are ever fetched)
   const bool rec16 = counters[7] != 0u;  // fp16-storage rows (gsaj_common.h)
-  uint32_t id_nxt = 0u;  // thread t < 48: Gaussian id of the NEXT round's entry t, requested a round ahead of its row
-  {
-    const uint32_t lo0 = (hi - range.x > BWD_ROUND) ? hi - BWD_ROUND : range.x;
-    if (hi > range.x && lo0 + (uint32_t)tid < hi) id_nxt = point_list[lo0 + tid];
+  // Staging, software-pipelined over the rounds.  A round's 48 rows are gathered through two dependent loads (id, then the row
+  // it names): waited for at the round's start, that latency was a tenth of a wave's life (per-round phase times of the
+  // trace build, tools/batch_trace.py).  Now thread (part, e) = (tid / 48, tid % 48), part < 4, owns ONE 16-byte piece of entry e
+  // -- the row's three float4s and the Gaussian's block offset -- requests round r+1's piece at the start of round r (its id
+  // was requested a round earlier still) and writes it to LDS at the start of round r+1: four registers per thread instead
+  // of a whole row, and nothing is waited for but the very first round.  (part = wave: which array a wave reads is decided by
+  // scalar code; every wave issues ONE 16-byte load per round from base(part) + offset(lane).)
+  const int part = __builtin_amdgcn_readfirstlane(wave), e = lane;
+  auto round_lo = [&](uint32_t h) { return (h - range.x > BWD_ROUND) ? h - BWD_ROUND : range.x; };
+  auto load_id = [&](uint32_t l, uint32_t h) -> uint32_t {  // id of entry e of the round [l, h)
+    // (no branch around the load: a lane without an entry reads the tile's first id -- the value a load leaves in its
+    // registers can stay in flight across the loop's back edge only if no copy merges it with another definition)
+    const bool has = e < BWD_ROUND && l + (uint32_t)e < h;
+    const uint32_t v = gsaj_load_u32_global(point_list + (has ? l + (uint32_t)e : range.x));
+    return has ? v : 0xffffffffu;
+  };
+  // base and stride of this wave's piece (wave-uniform).  The 16-byte load of the 4-byte block offset / the 8-byte rectangle reads
+  // on into the next elements of the same workspace array (its last element: into the carve's alignment gap / the next array).
+  const char *piece_base;
+  uint32_t piece_stride;
+  if (part == 3) piece_base = reinterpret_cast<const char *>(g.block_sums), piece_stride = 0u;
+  else if (!rec16) piece_base = reinterpret_cast<const char *>(g.splat + part), piece_stride = 16u * REC_F4;
+  else if (part < 2) piece_base = reinterpret_cast<const char *>(g.splat16 + part), piece_stride = 16u * REC16_F4;
+  else piece_base = reinterpret_cast<const char *>(g.scat), piece_stride = 8u;
+  auto load_piece = [&](uint32_t id) -> float4 {
+    const uint32_t i = id != 0xffffffffu ? id : 0u;  // (no entry: element 0, never used)
+    const size_t off = piece_stride ? (size_t)i * piece_stride : (size_t)(i / PRE_BLOCK) * 4u;
+    return gsaj_load_f4_unaligned(piece_base + off);
+  };
+  uint32_t id_cur = 0xffffffffu, id_nxt = 0xffffffffu;  // ids of entry e in the round being staged next / the one after
+  float4 piece = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (hi > range.x) {
+    const uint32_t lo0 = round_lo(hi);
+    id_cur = load_id(lo0, hi);
+    id_nxt = load_id(round_lo(lo0), lo0);
+    piece = load_piece(id_cur);
   }
 
 #ifdef GSAJ_BLOCK_TRACE
@@ -151,33 +184,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 #endif
   while (hi > range.x) {
     BWD_PH(6)
-    const uint32_t lo = (hi - range.x > BWD_ROUND) ? hi - BWD_ROUND : range.x;
+    const uint32_t lo = round_lo(hi);
     const int n = (int)(hi - lo);
-    if (tid < n) {
-      const uint32_t id = id_nxt;
-      float4 q0, q1, q2;
-      gsaj_load_row(g.splat, g.splat16, id, rec16, q0, q1, q2);
-      const uint32_t blk_first = g.block_sums[id / PRE_BLOCK];  // exclusive offset of the Gaussian's block (frame scan)
-      uint32_t x0, y0, w;
-      if (rec16) {
-        const uint2 sc = g.scat[id];
-        x0 = sc.x & 0xffffu, y0 = sc.y & 0xffffu, w = (sc.x >> 16) - x0;
+    // this round's pieces -> LDS.  Layout per entry: rec[3j] = {mean x, mean y, rect, first local slot}, rec[3j+1] = {conic
+    // PRE-SCALED for v_exp_f32 (gsaj_prescale_conic), opacity}, rec[3j+2] = {r, g, b, depth}; blk_first[j] = block offset
+    if (e < n) {
+      int e_ = e;  // (LDS addresses below are formed here, from the lane id, not carried through the loop in registers of their own)
+      asm volatile("" : "+v"(e_));
+      const int e = e_;
+      if (part == 3) {
+        blk_first[e] = __float_as_uint(piece.x);
+      } else if (!rec16) {
+        if (part == 1) {
+          const float3 kq = gsaj_prescale_conic(piece.x, piece.y, piece.z);
+          rec[e * REC_F4 + 1] = make_float4(kq.x, kq.y, kq.z, piece.w);
+        } else {
+          rec[e * REC_F4 + part] = piece;
+        }
       } else {
-        const uint32_t rp = __float_as_uint(q2.w);
-        x0 = rp & 1023u, y0 = (rp >> 10) & 1023u, w = rp >> 20;
+        float *r = reinterpret_cast<float *>(rec + e * REC_F4);
+        if (part == 0) {  // {mean x, mean y, depth, first}
+          r[0] = piece.x, r[1] = piece.y, r[3] = piece.w, r[11] = piece.z;
+        } else if (part == 1) {  // half2(a, b), half2(c, opacity), half2(r, g), half2(b, 0)
+          const float2 ab = gsaj_unpack_h2(__float_as_uint(piece.x)), co = gsaj_unpack_h2(__float_as_uint(piece.y));
+          const float2 rg = gsaj_unpack_h2(__float_as_uint(piece.z)), bz = gsaj_unpack_h2(__float_as_uint(piece.w));
+          const float3 kq = gsaj_prescale_conic(ab.x, ab.y, co.x);
+          rec[e * REC_F4 + 1] = make_float4(kq.x, kq.y, kq.z, co.y);
+          r[8] = rg.x, r[9] = rg.y, r[10] = bz.x;
+        } else if (part == 2) {  // the rectangle, packed as the fp32 rows carry it: x0 | y0 << 10 | w << 20
+          const uint32_t sx = __float_as_uint(piece.x), sy = __float_as_uint(piece.y);
+          const uint32_t x0 = sx & 0xffffu, y0 = sy & 0xffffu, w = (sx >> 16) - x0;
+          r[2] = __uint_as_float(x0 | (y0 << 10) | (w << 20));
+        }
       }
-      // emission slot: where this instance's partial gradients go (Gaussian-major, tiles of the rectangle in row order)
-      const uint32_t emit = blk_first + __float_as_uint(q0.w) + ((uint32_t)ty - y0) * w + ((uint32_t)tx - x0);
-      // the conic is staged PRE-SCALED for v_exp_f32 (gsaj_prescale_conic), like the forward's packed entries: the per-entry loop
-      // below then spends no instructions on it; phase 2 (once per 8 entries) scales back
-      const float3 kq = gsaj_prescale_conic(q1.x, q1.y, q1.z);
-      rec[tid * REC_F4 + 0] = make_float4(q0.x, q0.y, q0.z, __uint_as_float(id));
-      rec[tid * REC_F4 + 1] = make_float4(kq.x, kq.y, kq.z, q1.w);
-      rec[tid * REC_F4 + 2] = make_float4(q2.x, q2.y, q2.z, __uint_as_float(emit));
     }
-    if (lo > range.x) {  // the next round's ids
-      const uint32_t lo2 = (lo - range.x > BWD_ROUND) ? lo - BWD_ROUND : range.x;
-      if (lo2 + (uint32_t)tid < lo) id_nxt = point_list[lo2 + tid];
+    {  // the next round's pieces, and the ids of the round after it (unconditional: past the list's head the rounds are empty)
+      const uint32_t lo2 = round_lo(lo);
+      id_cur = id_nxt;
+      id_nxt = load_id(round_lo(lo2), lo2);
+      piece = load_piece(id_cur);
     }
     {
       float4 *z = reinterpret_cast<float4 *>(acc);
@@ -295,7 +340,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
             // (backward.cu:799-823, colour and depth alike): the four recurrences accum_rec <- alpha c + (1 - alpha) accum_rec
             // collapse into ONE for the scalar s = accum_rec . g, s <- s + alpha (c . g - s) -- 6 VALU operations per entry
             // instead of 12, same value up to fp32 rounding (the dot product is linear in accum_rec)
-            const float cg = r2.x * gC0 + r2.y * gC1 + r2.z * gC2 + r0.z * gD;
+            const float cg = r2.x * gC0 + r2.y * gC1 + r2.z * gC2 + r2.w * gD;
             const float dd = cg - accS;
             const float dL_dalpha = dd * T - Tf_bg * inv1ma;
             accS += alpha * dd;
@@ -313,21 +358,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     BWD_PH(2)
     __syncthreads();
     BWD_PH(3)
-    if (tid < n) {
-      float t[ACC_C];
+    if (part < 3 && e < n) {  // wave `part`, lane e: float4 `part` of entry e's row = partials 4 part .. 4 part + 3
+      float t[4];
 #pragma unroll
-      for (int c = 0; c < ACC_C; c++) {
-        const float *a = acc + c * ACC_STRIDE + tid;
+      for (int c = 0; c < 4; c++) {
+        const float *a = acc + min(part * 4 + c, ACC_C - 1) * ACC_STRIDE + e;
         t[c] = ((a[0] + a[ACC_C * ACC_STRIDE]) + a[2 * ACC_C * ACC_STRIDE]) + a[3 * ACC_C * ACC_STRIDE];  // fixed order
       }
-      const float4 s0 = make_float4(t[0], t[1], t[2], t[3]), s1 = make_float4(t[4], t[5], t[6], t[7]),
-                   s2 = make_float4(t[8], t[9], 0.f, 0.f);
-      const uint32_t emit = __float_as_uint(rec[tid * REC_F4 + 2].w);  // emission slot
-      float4 *dst = inst_grad + (size_t)emit * REC_F4;
-      dst[0] = s0;
-      dst[1] = s1;
-      dst[2] = s2;
-      reached[emit] = 1;
+      if (part == 2) t[2] = t[3] = 0.f;
+      // emission slot: where this instance's partial gradients go (Gaussian-major, tiles of the rectangle in row order)
+      const float4 q0 = rec[e * REC_F4 + 0];
+      const uint32_t rp = __float_as_uint(q0.z);
+      const uint32_t x0 = rp & 1023u, y0 = (rp >> 10) & 1023u, w = rp >> 20;
+      const uint32_t emit = blk_first[e] + __float_as_uint(q0.w) + ((uint32_t)ty - y0) * w + ((uint32_t)tx - x0);
+      inst_grad[(size_t)emit * REC_F4 + part] = make_float4(t[0], t[1], t[2], t[3]);
+      if (part == 0) reached[emit] = 1;
     }
     BWD_PH(4)
     __syncthreads();
