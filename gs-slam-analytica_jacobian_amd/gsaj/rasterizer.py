@@ -249,6 +249,43 @@ def _fwd_flags(record_bits):
     return FWD_RECORDS_FP16 if record_bits == 16 else 0
 
 
+class ArenaWatch:
+    """Growing the binning arena BEFORE a frame overflows it, without a host synchronisation.
+
+    An asynchronous forward that needs more instances than the arena holds is aborted on the device and repeated after a
+    blocking re-size -- and a SLAM map grows by construction.  After every `every`-th asynchronous forward the K views' frame
+    counters (instances R, error flags, longest tile list: 16 bytes per view) are copied to pinned host memory on the stream
+    (non-blocking) and an event is recorded; a later call that finds the event complete looks at them -- a query, never a wait --
+    and re-allocates the arena (x1.5 of the largest R) once R passes `grow_at` of the capacity.  The figures are a few frames old
+    by then: the head room covers a map that grows a few per cent per frame; a jump beyond it still takes the abort path.
+    Not used inside a stream capture (a captured graph holds the arena's address)."""
+
+    def __init__(self, img, K, img_stride, counters_offset, every=4, grow_at=0.75):
+        self.K, self.every, self.grow_at = int(K), int(every), float(grow_at)
+        i32 = img.view(torch.int32)
+        self.dev_counters = torch.as_strided(i32, (self.K, 4), (img_stride // 4, 1), counters_offset // 4)
+        self.host = torch.zeros((self.K, 4), dtype=torch.int32).pin_memory()
+        self.event = torch.cuda.Event()
+        self.pending, self.calls = False, 0
+        self.grown = 0  # how many times the arena was re-allocated ahead of an overflow
+
+    def post(self):
+        """After an asynchronous forward was enqueued."""
+        self.calls += 1
+        if self.pending or self.calls % self.every or torch.cuda.is_current_stream_capturing():
+            return
+        self.host.copy_(self.dev_counters, non_blocking=True)
+        self.event.record()
+        self.pending = True
+
+    def poll(self):
+        """Before an asynchronous forward: (largest R, longest tile list) of a frame a few calls back, or None."""
+        if not self.pending or torch.cuda.is_current_stream_capturing() or not self.event.query():
+            return None
+        self.pending = False
+        return int(self.host[:, 0].max()), int(self.host[:, 2].max())
+
+
 class FrameContext:
     """Pre-allocated outputs and workspaces for repeated forward+backward passes over one scene
     size (the tracking / mapping inner loop): no allocation and two C-ABI calls per step.
@@ -273,6 +310,8 @@ class FrameContext:
         self.capacity = 0  # > 0 once an arena has been sized: enables forward(sync=False)
         self.tile_list_capacity = 0  # tile-list length the LDS sort of asynchronous frames is sized for (0: the maximum, 16384);
                                      # a longer list is sorted in chunks + merge passes (slower, never wrong)
+        self.watch = ArenaWatch(self.img, 1, self.img.numel(), self.abort_flag_ptr() - 16 - self.img.data_ptr())  # (counters[4] = the abort word)
+        self.auto_grow = True  # asynchronous frames: grow the arena ahead of an overflow (ArenaWatch)
         # per-Gaussian parameter gradients live in ONE flat bucket (field-major) so that a multi-GPU
         # mapping step can all-reduce it with a single collective (gsaj.keyframe_shard); `grad_slots`
         # buckets let the collective of step i overlap the kernels of step i+1
@@ -310,6 +349,19 @@ class FrameContext:
         off = self.abort_flag_ptr() - self.img.data_ptr()
         return self.img[off:off + 4].view(torch.int32)
 
+    def _grow_ahead(self):
+        """(asynchronous frames) re-allocate the arena if a recent frame came close to filling it; no host synchronisation."""
+        seen = self.watch.poll() if self.auto_grow else None
+        if seen is None:
+            return
+        R, longest = seen
+        if R > self.watch.grow_at * self.capacity:
+            self.capacity = int(R * 1.5) + 1024
+            self.binning = torch.empty(self.lib.gsaj_binning_workspace_bytes(self.capacity), device=self.dev, dtype=torch.uint8)
+            self.watch.grown += 1
+        if longest > self.tile_list_capacity:
+            self.tile_list_capacity = min(SORT_CAP, int(1.1 * longest) + 1)
+
     def _ensure_binning(self, R):
         need = self.lib.gsaj_binning_workspace_bytes(R)
         if self.binning.numel() < need:
@@ -346,6 +398,7 @@ class FrameContext:
                  rotations, cov3D_precomp, scale_modifier, sync):
         lib, st = self.lib, _stream(self.dev)
         if not sync and self.capacity > 0:
+            self._grow_ahead()
             _lib.check(lib.gsaj_rasterize_forward_async(
                 self.P, int(sh_degree), self.M, _ptr(bg), self.W, self.H, _ptr(means3D), _ptr(shs), _ptr(colors_precomp),
                 _ptr(opacities), _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp),
@@ -354,6 +407,7 @@ class FrameContext:
                 self.n_touched.data_ptr(), self.geom.data_ptr(), self.binning.data_ptr(), self.binning.numel(),
                 self.capacity, self.tile_list_capacity, self.img.data_ptr(), self.flags, st), "gsaj_rasterize_forward_async")
             self.R = self.capacity  # what the backward must be given (arena carving)
+            self.watch.post()
             return self.R
         _lib.check(lib.gsaj_forward_preprocess(
             self.P, int(sh_degree), self.M, self.W, self.H, _ptr(means3D), _ptr(shs), _ptr(colors_precomp),
@@ -387,6 +441,7 @@ class FrameContext:
         if not hasattr(self, "loss_ws"):
             self.loss_ws = torch.empty(self.lib.gsaj_fused_loss_workspace_bytes(self.W, self.H), device=self.dev, dtype=torch.uint8)
         with torch.cuda.device(self.dev):
+            self._grow_ahead()
             _lib.check(self.lib.gsaj_rasterize_forward_loss(
                 self.P, int(sh_degree), self.M, _ptr(bg), self.W, self.H, _ptr(means3D), _ptr(shs), _ptr(colors_precomp),
                 _ptr(opacities), _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp),
@@ -397,6 +452,7 @@ class FrameContext:
                 float(loss["rgb_boundary_threshold"]), _ptr(loss["gt_color"]), _ptr(loss.get("gt_depth")), _ptr(loss.get("grad_mask")),
                 _ptr(loss.get("exposure_a")), _ptr(loss.get("exposure_b")), loss["scalars"].data_ptr(), self.loss_ws.data_ptr(),
                 _stream(self.dev)), "gsaj_rasterize_forward_loss")
+            self.watch.post()
         self.R = self.capacity
         return self.R
 
@@ -488,6 +544,8 @@ class BatchContext:
         self.img = torch.zeros(K * self.img_stride, **byte)  # zeroed once: holds the sticky abort counters
         self.binning = torch.empty(0, **byte)
         self.capacity, self.tile_list_capacity, self.bin_stride = 0, 0, 0
+        self.watch = ArenaWatch(self.img, self.K, self.img_stride, lib.gsaj_forward_abort_flag(W, H, self.img.data_ptr()) - 16 - self.img.data_ptr())
+        self.auto_grow = True  # sync=False windows: grow the arena ahead of an overflow (ArenaWatch)
         self.buckets, self.slots = [], []
         for _ in range(max(1, grad_slots)):
             bucket = torch.zeros(bucket_numel(P, M, has_scales, K * n_windows), **f)
@@ -582,8 +640,17 @@ class BatchContext:
              rotations, cov3D_precomp, scale_modifier)
         if self.capacity == 0:
             self._size(max(4096, 12 * self.P))
+        elif not sync and self.auto_grow:
+            seen = self.watch.poll()
+            if seen is not None:
+                if seen[0] > self.watch.grow_at * self.capacity:
+                    self._size(int(1.5 * seen[0]) + 1024)
+                    self.watch.grown += 1
+                if seen[1] > self.tile_list_capacity > 0:
+                    self.tile_list_capacity = min(SORT_CAP, int(1.1 * seen[1]) + 1)
         self._launch(*a)
         if not sync:
+            self.watch.post()
             return None
         st = self.status()
         if any(ab for _, _, ab in st):

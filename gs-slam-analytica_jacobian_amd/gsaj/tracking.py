@@ -147,9 +147,11 @@ class DeviceTracker:
                 elif not self.use_graph:
                     self._eager(False)
                 else:
+                    self.ctx._grow_ahead()  # (a replayed graph calls no forward: the arena watch runs here, outside the capture)
                     if self._graphs is None or self._graphs[2] != self.ctx.binning.data_ptr():
                         self._capture()  # (again if the arena was re-allocated: the graph holds its address)
                     self._graphs[0].replay()
+                    self.ctx.watch.post()
                     if self._graphs[1] is not None:
                         tbs.allreduce_pose_terms(self.packed, self.group)
                         self._graphs[1].replay()

@@ -217,12 +217,15 @@ def assert_grads_close(g, gref, tag, st=None, projmatrix_raw=None, tol=GRAD_TOL,
         Gaussians: the three terms of d(conic)/d(cov2D) cancel inside the chain, which rounds every fp32 evaluation alike but is
         invisible to an input perturbation);
     (C) end to end against the full oracle, max |err| relative to the tensor's max: <= `tol` (GRAD_TOL) over the Gaussians no
-        borderline pixel touches, <= GRAD_TOL_FLIPPED over all of them and for dL/dtau summed over Gaussians (a flipped
-        contributor moves a small Gaussian's gradient by one pixel's worth -- bounded exactly in (A))."""
+        borderline pixel touches; over ALL of them, row by row, within (A)'s bounds on the ten sums carried through the chain (it
+        is linear in them: nine fp64 chain evaluations give |J| bound exactly) plus (B)'s allowance -- a flipped contributor
+        moves a small Gaussian's gradient by one pixel's worth, and that is now priced per Gaussian instead of by a constant;
+        GRAD_TOL_FLIPPED stays as the net for callers without the oracle state and for dL/dtau summed over the Gaussians."""
     from oracle import oracle as orc
 
     got = {nm: x for nm, x in zip(GRAD_NAMES, g) if x is not None and nm not in skip}
     worst = {}
+    chain_allow, chain_err32 = {}, {}  # per chain tensor, per row: what (B) allows / the oracle's own fp32 chain error
     chain_noise = {}  # per chain tensor: how far the oracle's own fp32 chain is from the fp64 chain (tensor-max relative)
     if st is not None and projmatrix_raw is not None and "dL_dmean2D" in got:  # (B)
         sums = (_np(got["dL_dmean2D"]), _np(got["dL_dconic"]), _np(got["dL_dcolor"]), _np(got["dL_ddepth"]))
@@ -236,6 +239,7 @@ def assert_grads_close(g, gref, tag, st=None, projmatrix_raw=None, tol=GRAD_TOL,
             err = np.abs(x - t).max(axis=1)
             err32 = noise32[nm]  # the oracle's fp32 chain on the SAME row, worst of 1 + 4 samples
             allowed = np.maximum(np.maximum(CHAIN_ROW_TOL * scale, CHAIN_COND_K * sens[nm]), CHAIN_K * err32)
+            chain_allow[nm], chain_err32[nm] = allowed, err32
             worst[nm + "/chain_row"] = float((err / scale).max())
             worst[nm + "/chain_row_oracle32"] = row_rel_err(o32[nm], truth[nm], floor=CHAIN_FLOOR)
             worst[nm + "/chain_row_over_allowed"] = float((err / allowed).max())
@@ -252,6 +256,30 @@ def assert_grads_close(g, gref, tag, st=None, projmatrix_raw=None, tol=GRAD_TOL,
     em = gref.get("error_model")
     # Gaussians no borderline pixel touches: their sums involve no cut-off decision that could fall either way
     clean = (em["flip_budget"].max(axis=1) == 0) if em is not None else None
+    # What layer (A) allows the ten compositor sums to differ by, carried through the per-Gaussian chain -- which is LINEAR in
+    # the sums, so chain64(bound_k e_k) is column k of |J| bound exactly: per row of every chain output, the largest end-to-end
+    # difference two evaluations inside (A)'s bounds can show.  With it (C) needs no constant for the Gaussians a borderline
+    # pixel touches: |device - oracle| <= propagated (A) bound + the chain allowance of (B) + the oracle's own fp32 chain error.
+    derived = None
+    if em is not None and chain_allow and all(k in got for k in ("dL_dmean2D", "dL_dconic", "dL_dopacity", "dL_dcolor", "dL_ddepth")):
+        P = gref["dL_dopacity"].shape[0]
+        mass, cond, flip = (em[k].astype(np.float64) for k in ("term_mass", "cond_slack", "flip_budget"))
+        want10 = compositor_sums(gref, P)
+        bound10 = MASS_TOL * mass + COND_K * cond + FLIP_K * flip + 1e-9 * np.abs(want10).max(axis=0, keepdims=True) + 1e-37
+        derived = {nm: 0.0 for nm in chain_allow}
+        for k in (0, 1, 2, 3, 4, 6, 7, 8, 9):  # (5 = opacity: not a chain input)
+            m2, cn, dc, dd = np.zeros((P, 3)), np.zeros((P, 4)), np.zeros((P, 3)), np.zeros((P, 1))
+            if k < 2:
+                m2[:, k] = bound10[:, k]
+            elif k < 5:
+                cn[:, (0, 1, 3)[k - 2]] = bound10[:, k]
+            elif k < 9:
+                dc[:, k - 6] = bound10[:, k]
+            else:
+                dd[:, 0] = bound10[:, k]
+            col = orc.chain(st, m2, cn, dc, dd, projmatrix_raw, f64=True)
+            for nm in chain_allow:
+                derived[nm] = derived[nm] + np.abs(col[nm].reshape(P, -1)).max(axis=1)
     for nm, x in got.items():  # (C)
         want = np.asarray(gref[nm])
         if want.size == 0:
@@ -265,6 +293,20 @@ def assert_grads_close(g, gref, tag, st=None, projmatrix_raw=None, tol=GRAD_TOL,
         if clean is not None and nm != "dL_dtau_sum" and clean.any():
             worst[nm + "/clean"] = e = float(np.abs(x[clean].astype(np.float64) - want[clean]).max() / (np.abs(want).max() + 1e-30))
             assert e < max(tol, CHAIN_K * chain_noise.get(nm, 0.0)), (tag, nm, "Gaussians untouched by borderline pixels", e, chain_noise.get(nm))
+        if derived is not None and nm in chain_allow:  # every Gaussian, flipped or not, against ITS propagated bound
+            P = want.shape[0]
+            err = np.abs(x.astype(np.float64) - want).reshape(P, -1).max(axis=1)
+            allowed = derived[nm] + chain_allow[nm] + chain_err32[nm] + tol * np.abs(want).max()
+            worst[nm + "/err_over_propagated_bound"] = float((err / allowed).max())
+            i = int(np.argmax(err / allowed))
+            assert err[i] <= allowed[i], (tag, nm, "Gaussian %d: end-to-end error %.3e above the compositor bounds carried through the chain %.3e "
+                                          "+ chain allowance %.3e + oracle fp32 chain error %.3e" % (i, err[i], derived[nm][i], chain_allow[nm][i], chain_err32[nm][i]))
+    if derived is not None and "dL_dtau_sum" in got and "dL_dtau" in chain_allow:
+        want = np.asarray(gref["dL_dtau_sum"], np.float64)
+        err = np.abs(_np(got["dL_dtau_sum"]).astype(np.float64).reshape(-1) - want.reshape(-1)).max()
+        allowed = float((derived["dL_dtau"] + chain_allow["dL_dtau"] + chain_err32["dL_dtau"]).sum()) + tol * np.abs(want).max()
+        worst["dL_dtau_sum/err_over_propagated_bound"] = float(err / allowed)
+        assert err <= allowed, (tag, "dL_dtau_sum", err, allowed)
     em = gref.get("error_model")
     if em is not None and all(k in got for k in ("dL_dmean2D", "dL_dconic", "dL_dopacity", "dL_dcolor", "dL_ddepth")):  # (A)
         P = gref["dL_dopacity"].shape[0]
