@@ -14,9 +14,11 @@
 #include "gsaj_common.h"
 #include <cfloat>
 #include <cstring>
-#include <rocprim/rocprim.hpp>
 
 #define KNN_BOX 256
+#define RS_TILE 2048   // keys per workgroup of the radix passes (one wave64: a tile is walked in list order, 64 keys at a time)
+#define RS_BITS 8
+#define RS_BUCKETS (1 << RS_BITS)
 
 struct KnnWS {
   float *bbox;         // [6] min xyz, max xyz
@@ -25,16 +27,8 @@ struct KnnWS {
   uint32_t *codes, *codes_sorted, *idx, *idx_sorted;
   float4 *sorted;      // [P] points in Morton order (w unused)
   float *boxes;        // [nbox][6]
-  void *sort_temp;
-  size_t sort_bytes;
+  uint32_t *hist;      // [RS_BUCKETS][ntile] digit counts of the radix pass under way, bucket-major; exclusive offsets after the scan
 };
-
-static size_t knn_sort_bytes(int P) {
-  size_t bytes = 0;
-  uint32_t *k = nullptr;
-  (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, k, k, (size_t)P, 0, 30, (hipStream_t)0);
-  return bytes;
-}
 
 static size_t knn_carve(void *base, int P, KnnWS *w) {
   char *p = (char *)(((uintptr_t)base + 255) & ~(uintptr_t)255);
@@ -49,8 +43,7 @@ static size_t knn_carve(void *base, int P, KnnWS *w) {
   w->idx_sorted = (uint32_t *)take(Pz * 4);
   w->sorted = (float4 *)take(Pz * sizeof(float4));
   w->boxes = (float *)take(nbox * 6 * sizeof(float));
-  w->sort_bytes = knn_sort_bytes(P);
-  w->sort_temp = take(w->sort_bytes);
+  w->hist = (uint32_t *)take((size_t)RS_BUCKETS * ((Pz + RS_TILE - 1) / RS_TILE) * 4);
   return (size_t)(p - (char *)base) + 256;
 }
 
@@ -136,6 +129,108 @@ __global__ __launch_bounds__(256) void k_knn_morton(int P, const float *__restri
   const uint32_t cz = prep_morton((uint32_t)(((z - mnz) / (mxz - mnz)) * 1023.f));
   w.codes[i] = cx | (cy << 1) | (cz << 2);
   w.idx[i] = (uint32_t)i;
+}
+
+// ---- the Morton sort: least-significant-digit radix sort of (code, index) pairs, 8 bits per pass (thrust::sort_by_key in the
+// reference, simple_knn.cu:211; a library radix sort up to round 2).  Three kernels per pass: per-tile digit counts, one
+// exclusive scan over (bucket, tile) -- bucket-major, so a key's offset is "keys of smaller digits anywhere + keys of its digit in
+// earlier tiles" --, and a scatter in which ONE wave walks its tile in list order, 64 keys at a time: the lanes holding the
+// same digit find each other with eight ballots, rank = the tile's running count of the digit + the peers on lower lanes.  Every
+// pass is therefore STABLE (ties keep their order, as a radix sort's must for the next digit to be meaningful), and the result
+// is the one any stable sort by code gives.  Map initialisation / densification path: throughput is not the point (10^6 points:
+// 4 passes x 3 short launches), having no library in the rasteriser's shared object is.
+__device__ __forceinline__ unsigned long long rs_peers(uint32_t digit, bool valid) {
+  unsigned long long m = __builtin_amdgcn_ballot_w64(valid);
+#pragma unroll
+  for (int b = 0; b < RS_BITS; b++) {
+    const unsigned long long bal = __builtin_amdgcn_ballot_w64((digit >> b) & 1u);
+    m &= ((digit >> b) & 1u) ? bal : ~bal;
+  }
+  return m;
+}
+
+__global__ __launch_bounds__(64) void k_rs_hist(int P, int ntile, int shift, const uint32_t *__restrict__ keys, uint32_t *__restrict__ hist) {
+  __shared__ uint32_t cnt[RS_BUCKETS];
+  const int lane = threadIdx.x, tile = blockIdx.x;
+  for (int d = lane; d < RS_BUCKETS; d += 64) cnt[d] = 0u;
+  __syncthreads();
+  const int beg = tile * RS_TILE, end = min(P, beg + RS_TILE);
+  for (int i = beg + lane; i < end; i += 64) atomicAdd(&cnt[(keys[i] >> shift) & (RS_BUCKETS - 1)], 1u);
+  __syncthreads();
+  for (int d = lane; d < RS_BUCKETS; d += 64) hist[(size_t)d * ntile + tile] = cnt[d];
+}
+
+__global__ __launch_bounds__(1024) void k_rs_scan(int n, uint32_t *__restrict__ hist) {  // exclusive scan, one workgroup
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry = 0u;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + tid;
+    const uint32_t v = i < n ? hist[i] : 0u;
+    uint32_t x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = (uint32_t)__shfl_up((int)x, o);
+      if (lane >= o) x += t;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    uint32_t before = carry;
+    for (int k = 0; k < wave; k++) before += wsum[k];
+    if (i < n) hist[i] = before + x - v;
+    __syncthreads();
+    if (tid == 1023) carry = before + x;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(64) void k_rs_scatter(int P, int ntile, int shift, const uint32_t *__restrict__ keys,
+                                                   const uint32_t *__restrict__ vals, uint32_t *__restrict__ keys_out,
+                                                   uint32_t *__restrict__ vals_out, const uint32_t *__restrict__ hist) {
+  __shared__ uint32_t run[RS_BUCKETS];  // where the tile's next key of each digit goes
+  const int lane = threadIdx.x, tile = blockIdx.x;
+  for (int d = lane; d < RS_BUCKETS; d += 64) run[d] = hist[(size_t)d * ntile + tile];
+  __syncthreads();
+  const int beg = tile * RS_TILE, end = min(P, beg + RS_TILE);
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (int i0 = beg; i0 < end; i0 += 64) {
+    const int i = i0 + lane;
+    const bool valid = i < end;
+    const uint32_t k = valid ? keys[i] : 0u, v = valid ? vals[i] : 0u;
+    const uint32_t d = (k >> shift) & (RS_BUCKETS - 1);
+    const unsigned long long peers = rs_peers(d, valid);
+    if (valid) {
+      const uint32_t dst = run[d] + (uint32_t)__popcll(peers & below);
+      keys_out[dst] = k;
+      vals_out[dst] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (valid && (peers & below) == 0ull) run[d] += (uint32_t)__popcll(peers);  // the digit's lowest lane
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+// Sorts the (codes, idx) pairs; the passes alternate between the two pairs of arrays, and w.codes_sorted / w.idx_sorted are
+// pointed at whichever pair holds the result.
+static int knn_radix_sort(int P, KnnWS &w, hipStream_t s) {
+  const int ntile = (P + RS_TILE - 1) / RS_TILE;
+  uint32_t *ka = w.codes, *va = w.idx, *kb = w.codes_sorted, *vb = w.idx_sorted;
+  for (int shift = 0; shift < 30; shift += RS_BITS) {
+    hipLaunchKernelGGL(k_rs_hist, dim3(ntile), dim3(64), 0, s, P, ntile, shift, ka, w.hist);
+    hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(1024), 0, s, RS_BUCKETS * ntile, w.hist);
+    hipLaunchKernelGGL(k_rs_scatter, dim3(ntile), dim3(64), 0, s, P, ntile, shift, ka, va, kb, vb, w.hist);
+    uint32_t *t = ka; ka = kb; kb = t;
+    t = va; va = vb; vb = t;
+  }
+  w.codes_sorted = ka;  // (an even number of passes: the result is back in the first pair of arrays)
+  w.idx_sorted = va;
+  GSAJ_HIP_CHECK(hipGetLastError());
+  return GSAJ_OK;
 }
 
 // gather into Morton order + per-box bounds (simple_knn.cu:76-117, 256-point boxes)
@@ -236,10 +331,30 @@ extern "C" int gsaj_dist2(int P, const float *points, float *mean_dists, void *k
   const unsigned nblk = (unsigned)((P + 255) / 256), nbox = (unsigned)((P + KNN_BOX - 1) / KNN_BOX);
   hipLaunchKernelGGL(k_knn_bbox, dim3(nblk), dim3(256), 0, s, P, points, w);
   hipLaunchKernelGGL(k_knn_morton, dim3(nblk), dim3(256), 0, s, P, points, w);
-  size_t bytes = w.sort_bytes;
-  GSAJ_HIP_CHECK(rocprim::radix_sort_pairs(w.sort_temp, bytes, w.codes, w.codes_sorted, w.idx, w.idx_sorted, (size_t)P, 0, 30, s));
+  {
+    const int rc = knn_radix_sort(P, w, s);
+    if (rc != GSAJ_OK) return rc;
+  }
   hipLaunchKernelGGL(k_knn_boxes, dim3(nbox), dim3(KNN_BOX), 0, s, P, points, w);
   hipLaunchKernelGGL(k_knn_mean_dist, dim3((P + 63) / 64), dim3(64), 0, s, P, w, mean_dists);
   GSAJ_HIP_CHECK(hipGetLastError());
+  return GSAJ_OK;
+}
+
+extern "C" int gsaj_debug_dist2_order(int P, void *knn_ws, uint32_t *codes_sorted, uint32_t *idx_sorted, void *stream) {
+  if (P <= 0 || !knn_ws || !codes_sorted || !idx_sorted) {
+    gsaj_set_error("gsaj_debug_dist2_order: invalid argument (P=%d)", P);
+    return GSAJ_ERR_INVALID_ARGUMENT;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  KnnWS w;
+  knn_carve(knn_ws, P, &w);
+  // (where knn_radix_sort leaves the result: passes alternate between the two pairs of arrays)
+  int passes = 0;
+  for (int shift = 0; shift < 30; shift += RS_BITS) passes++;
+  const uint32_t *k = (passes & 1) ? w.codes_sorted : w.codes, *v = (passes & 1) ? w.idx_sorted : w.idx;
+  GSAJ_HIP_CHECK(hipMemcpyAsync(codes_sorted, k, (size_t)P * 4, hipMemcpyDeviceToDevice, s));
+  GSAJ_HIP_CHECK(hipMemcpyAsync(idx_sorted, v, (size_t)P * 4, hipMemcpyDeviceToDevice, s));
+  GSAJ_HIP_CHECK(hipStreamSynchronize(s));
   return GSAJ_OK;
 }

@@ -62,6 +62,7 @@ SIGNATURES = {
     "gsaj_dense_tau": (c_int, [c_int, c_int, c_int] + [P] * 11 + [P, P, P]),
     "gsaj_dist2_workspace_bytes": (c_size_t, [c_int]),
     "gsaj_dist2": (c_int, [c_int, P, P, P, P]),
+    "gsaj_debug_dist2_order": (c_int, [c_int, P, P, P, P]),
     "gsaj_pose_state_floats": (c_int, []),
     "gsaj_pose_adam_step": (c_int, [P, P] + [c_float] * 8 + [P, P, P, P]),
     "gsaj_pose_adam_step_batch": (c_int, [c_int, P, P, P] + [c_float] * 8 + [P, P, P, c_size_t, P]),

@@ -386,6 +386,10 @@ int gsaj_pose_adam_step_batch(int K, const float *dL_dtau, const float *dL_dexpo
  * knn_ws: gsaj_dist2_workspace_bytes(P) bytes. */
 size_t gsaj_dist2_workspace_bytes(int P);
 int gsaj_dist2(int P, const float *points, float *mean_dists, void *knn_ws, void *stream);
+/* Tests only: the Morton order gsaj_dist2 left in its workspace -- the 30-bit codes in sorted order and the point index of every
+ * position (device arrays [P]; blocking).  The sort is this library's own stable radix sort (thrust::sort_by_key in the reference,
+ * simple_knn.cu:211): ascending codes, equal codes in ascending index order. */
+int gsaj_debug_dist2_order(int P, void *knn_ws, uint32_t *codes_sorted, uint32_t *idx_sorted, void *stream);
 
 /* ---- dense analytic path (NumPy-path semantics) ------------------ */
 size_t gsaj_dense_workspace_bytes(int N, int W, int H);

@@ -45,3 +45,40 @@ def test_dist2_is_invariant_to_point_order():
     perm = rng.permutation(3000)
     a, b = _run(p), _run(p[perm])
     np.testing.assert_array_equal(a[perm], b)   # exact search: bitwise the same whatever the Morton tie-breaking
+
+
+@pytest.mark.parametrize("n,kind", [(1, "u"), (63, "u"), (2049, "u"), (50000, "u"), (30000, "dups"), (300000, "grid")])
+def test_the_morton_sort_is_a_stable_sort_by_code(n, kind):
+    """The library's own radix sort (no rocPRIM any more): ascending 30-bit codes, a permutation of the points, equal codes in
+    ascending index order (= what a stable sort of the (code, index) pairs in index order gives; thrust::sort_by_key in the
+    reference, simple_knn.cu:211), over every tile / pass boundary (2048-key tiles, 8-bit digits)."""
+    import torch
+    from gsaj import _lib
+
+    rng = np.random.default_rng(n)
+    if kind == "u":
+        p = rng.uniform(-2, 3, (n, 3))
+    elif kind == "dups":
+        p = np.repeat(rng.uniform(-1, 1, (n // 100, 3)), 100, axis=0)  # long runs of equal codes, across tiles
+    else:
+        p = rng.integers(0, 8, (n, 3)).astype(np.float64)               # 512 distinct codes only
+    lib, dev = _lib.load(), torch.device("cuda:0")
+    pts = torch.as_tensor(p, dtype=torch.float32, device=dev).contiguous()
+    out = torch.empty(n, dtype=torch.float32, device=dev)
+    ws = torch.empty(lib.gsaj_dist2_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    _lib.check(lib.gsaj_dist2(n, pts.data_ptr(), out.data_ptr(), ws.data_ptr(), st), "gsaj_dist2")
+    codes, idx = torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev)
+    _lib.check(lib.gsaj_debug_dist2_order(n, ws.data_ptr(), codes.data_ptr(), idx.data_ptr(), st), "gsaj_debug_dist2_order")
+    codes, idx = codes.cpu().numpy().astype(np.int64), idx.cpu().numpy().astype(np.int64)
+    assert (codes >= 0).all() and (codes < 2 ** 30).all()
+    assert (np.diff(codes) >= 0).all()
+    assert np.array_equal(np.sort(idx), np.arange(n))
+    same = np.diff(codes) == 0
+    assert (np.diff(idx)[same] > 0).all()  # stable
+    if kind != "u":
+        assert same.sum() > n // 2  # (the case does exercise ties)
+    # points that share all three coordinates share a code: the code is a function of the point
+    key = {}
+    for c, i in zip(codes[:5000], idx[:5000]):
+        assert key.setdefault(tuple(p[i].astype(np.float32)), c) == c
