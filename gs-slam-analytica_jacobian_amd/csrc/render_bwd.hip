@@ -180,6 +180,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 
 #ifdef GSAJ_BLOCK_TRACE
   unsigned ph_[7] = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  unsigned tr_flushes = 0u, tr_slots = 0u;  // phase-2 batches of this wave, and the accepted entries in them
   unsigned long long pht_ = wall_clock64();
 #endif
   while (hi > range.x) {
@@ -248,6 +249,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
 
       // ---- phase 2: moments of the queued (w, u) rows -> per-entry totals in this wave's acc slots ----
       auto flush = [&]() {
+#ifdef GSAJ_BLOCK_TRACE
+        tr_flushes++;
+        tr_slots += (unsigned)nslot;
+#endif
         // Lane (slot s, pixel row y): the row's 8 pixels sit at x' = -3.5 .. 3.5 around the quadrant centre column, so
         // three running sums of w (1, x', x'^2) give every second moment of the row about the Gaussian's mean:
         // dx = ax - x' (ax = mean x - centre column), dy constant along the row.  Slots beyond nslot hold stale rows;
@@ -386,7 +391,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
       g_trace_bwdph[4 * tw_ + 0] = ((unsigned long long)ph_[0] << 32) | ph_[1];
       g_trace_bwdph[4 * tw_ + 1] = ((unsigned long long)ph_[2] << 32) | ph_[3];
       g_trace_bwdph[4 * tw_ + 2] = ((unsigned long long)ph_[4] << 32) | ph_[5];
-      g_trace_bwdph[4 * tw_ + 3] = ph_[6];
+      g_trace_bwdph[4 * tw_ + 3] = ph_[6] | ((unsigned long long)tr_flushes << 32) | ((unsigned long long)tr_slots << 44);
     }
   }
 #endif

@@ -82,6 +82,8 @@ def bwd_phases(lib, n):
     lo32 = np.uint64(0xffffffff)
     ph = np.stack([raw[:, 0] >> np.uint64(32), raw[:, 0] & lo32, raw[:, 1] >> np.uint64(32), raw[:, 1] & lo32, raw[:, 2] >> np.uint64(32),
                    raw[:, 2] & lo32, raw[:, 3] & lo32], 1).astype(np.int64) * 0.01
+    flushes, slots = ((raw[:, 3] >> np.uint64(32)) & np.uint64(0xfff)).astype(np.int64), (raw[:, 3] >> np.uint64(44)).astype(np.int64)
+    print("      bwd phase-2 batches per wave %.1f, accepted entries per wave %.1f -> %.2f of 8 slots filled on average" % (flushes.mean(), slots.mean(), slots.sum() / max(1, 8 * flushes.sum())))
     names = "stage (row gather, zero acc) / barrier 1 / phases 1+2 / barrier 2 / merge + row stores / barrier 3 / loop head"
     for label, sel in (("wave 0", np.arange(n) % 4 == 0), ("waves 1-3", np.arange(n) % 4 != 0)):
         print("      bwd %s, us per wave (mean): %s = %s  (sum %.1f)" % (label, names, " / ".join("%.1f" % x for x in ph[sel].mean(0)), ph[sel].sum(1).mean()))
