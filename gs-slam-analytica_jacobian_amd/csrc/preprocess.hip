@@ -648,26 +648,99 @@ __device__ __forceinline__ uint64_t key_mirror(uint64_t k, int lane) {
 
 // The network is the ALL-ASCENDING form of the bitonic sort: the merge of two sorted runs of length K/2 opens with a "flip"
 // (element i against element K - 1 - i of the block) and continues with the half-cleaners of stride K/4 ... 1, every comparator
-// putting the smaller key at the lower index.  Keys past the end of a list are +inf and an all-ascending comparator never
-// moves +inf down: whole chunks, merges and comparators that would touch only padding are skipped, so a list of 315 keys costs
+// putting the smaller key at the lower index.  Keys past the end of a list are KEY_INF and an all-ascending comparator never
+// moves KEY_INF down: whole chunks, merges and comparators that would touch only padding are skipped, so a list of 315 keys costs
 // what 384 keys cost, not 512 (the alternating-direction form of rounds 1-2 had to sort the padding too).
 //
+// A comparator is v_min_f64 + v_max_f64.  A key (depth bits << 32 | id) read as a double has sign 0 and an exponent field
+// below 0x7F8 (the depth is a finite positive float), i.e. it is a positive normal double, and positive doubles order as their
+// bit patterns do: min / max of the doubles ARE the smaller / larger key, bit for bit, in one full-rate instruction each -- where
+// the integer form is a 64-bit compare and two selects per key kept (measured: all of these issue at ~4.3 cycles).  The padding key
+// is the largest finite double (~0 would be a NaN, which min / max drop).  Written as instructions: through fmin() / fmax() the
+// compiler first quiets a possible signalling NaN with an extra v_max_f64 x, x.
+#define KEY_INF 0x7FEFFFFFFFFFFFFFull
+__device__ __forceinline__ void key_minmax(uint64_t a, uint64_t b, uint64_t &lo, uint64_t &hi) {
+  double l, h;
+  asm("v_min_f64 %0, %2, %3\n\tv_max_f64 %1, %2, %3" : "=&v"(l), "=&v"(h) : "v"(__longlong_as_double((long long)a)), "v"(__longlong_as_double((long long)b)));
+  lo = (uint64_t)__double_as_longlong(l);
+  hi = (uint64_t)__double_as_longlong(h);
+}
+__device__ __forceinline__ uint64_t key_min(uint64_t a, uint64_t b) {
+  double l;
+  asm("v_min_f64 %0, %1, %2" : "=v"(l) : "v"(__longlong_as_double((long long)a)), "v"(__longlong_as_double((long long)b)));
+  return (uint64_t)__double_as_longlong(l);
+}
+__device__ __forceinline__ uint64_t key_max(uint64_t a, uint64_t b) {
+  double h;
+  asm("v_max_f64 %0, %1, %2" : "=v"(h) : "v"(__longlong_as_double((long long)a)), "v"(__longlong_as_double((long long)b)));
+  return (uint64_t)__double_as_longlong(h);
+}
+// lanes whose bit J is clear hold the lower-indexed key of their pair
+template <int J>
+__device__ __forceinline__ constexpr uint64_t lower_lanes() {
+  return J == 1 ? 0x5555555555555555ull : J == 2 ? 0x3333333333333333ull : J == 4 ? 0x0F0F0F0F0F0F0F0Full
+       : J == 8 ? 0x00FF00FF00FF00FFull : J == 16 ? 0x0000FFFF0000FFFFull : 0x00000000FFFFFFFFull;
+}
+// The comparators of one stage on the lane's two keys: A <- min(XA, YA) in the lanes of `lower`, max(XA, YA) in the others; B
+// likewise.  The two halves run under complementary EXEC masks (scalar constants), so no per-lane select is spent: four VALU
+// instructions for the two keys.  (All 64 lanes are active wherever the sort calls this; s_nop: a DPP instruction may follow, and
+// it needs five wait states after a scalar write of EXEC that the compiler cannot see.)
+__device__ __forceinline__ void key_stage(uint64_t &A, uint64_t XA, uint64_t YA, uint64_t &B, uint64_t XB, uint64_t YB, uint64_t lower) {
+  double a, b2;
+  uint64_t save;
+  asm volatile("s_mov_b64 %[sv], exec\n\t"
+               "s_and_b64 exec, %[sv], %[lo]\n\t"
+               "v_min_f64 %[a], %[xa], %[ya]\n\t"
+               "v_min_f64 %[b], %[xb], %[yb]\n\t"
+               "s_andn2_b64 exec, %[sv], %[lo]\n\t"
+               "v_max_f64 %[a], %[xa], %[ya]\n\t"
+               "v_max_f64 %[b], %[xb], %[yb]\n\t"
+               "s_mov_b64 exec, %[sv]\n\t"
+               "s_nop 4"
+               : [a] "=&v"(a), [b] "=&v"(b2), [sv] "=&s"(save)
+               : [xa] "v"(__longlong_as_double((long long)XA)), [ya] "v"(__longlong_as_double((long long)YA)),
+                 [xb] "v"(__longlong_as_double((long long)XB)), [yb] "v"(__longlong_as_double((long long)YB)), [lo] "s"(lower)
+               : "scc");
+  A = (uint64_t)__double_as_longlong(a);
+  B = (uint64_t)__double_as_longlong(b2);
+}
+// the two keys of lanes l and l ^ J for J = 32, 16: v_permlane*_swap of the key with a copy of itself leaves the lower lane's key
+// in one register pair and the upper lane's in the other, in BOTH lanes -- the comparator needs no "which is mine" select
+template <int J>
+__device__ __forceinline__ void key_both(uint64_t k, uint64_t &of_lower, uint64_t &of_upper) {
+  const uint32_t hi = (uint32_t)(k >> 32), lo = (uint32_t)k;
+  gsaj_u32x2 rh, rl;
+  if (J == 32) {
+    rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);  // r[0] = [lo half | lo half], r[1] = [hi half | hi half]
+    rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    of_lower = ((uint64_t)rh[0] << 32) | rl[0];
+    of_upper = ((uint64_t)rh[1] << 32) | rl[1];
+  } else {
+    rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);  // r[0] = rows [0,0,2,2], r[1] = rows [1,1,3,3]
+    rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    of_lower = ((uint64_t)rh[0] << 32) | rl[0];
+    of_upper = ((uint64_t)rh[1] << 32) | rl[1];
+  }
+}
 // one half-cleaner stage of stride J < 64 on the two keys a lane holds (indices base + lane and base + 64 + lane)
 template <int J>
 __device__ __forceinline__ void sort_stage(uint64_t &A, uint64_t &B, int lane) {
-  const uint64_t PA = ((uint64_t)lane_xor<J>((uint32_t)(A >> 32), lane) << 32) | lane_xor<J>((uint32_t)A, lane);
-  const uint64_t PB = ((uint64_t)lane_xor<J>((uint32_t)(B >> 32), lane) << 32) | lane_xor<J>((uint32_t)B, lane);
-  const bool lower = (lane & J) == 0;  // this lane holds the lower-indexed key of the pair: it keeps the smaller key
-  A = ((A < PA) == lower) ? A : PA;
-  B = ((B < PB) == lower) ? B : PB;
+  if constexpr (J >= 16) {
+    uint64_t al, au, bl, bu;
+    key_both<J>(A, al, au);
+    key_both<J>(B, bl, bu);
+    key_stage(A, al, au, B, bl, bu, lower_lanes<J>());
+  } else {
+    const uint64_t PA = ((uint64_t)lane_xor<J>((uint32_t)(A >> 32), lane) << 32) | lane_xor<J>((uint32_t)A, lane);
+    const uint64_t PB = ((uint64_t)lane_xor<J>((uint32_t)(B >> 32), lane) << 32) | lane_xor<J>((uint32_t)B, lane);
+    key_stage(A, A, PA, B, B, PB, lower_lanes<J>());
+  }
 }
 // half-cleaners of stride J, J/2, ..., 1 (J = 64: the in-lane comparator between a lane's two keys first)
 template <int J>
 __device__ __forceinline__ void merge_strides(uint64_t &A, uint64_t &B, int lane) {
   if constexpr (J == 64) {
-    const uint64_t lo = A < B ? A : B, hi = A < B ? B : A;
-    A = lo;
-    B = hi;
+    key_minmax(A, B, A, B);
   } else {
     sort_stage<J>(A, B, lane);
   }
@@ -678,14 +751,12 @@ template <int K>
 __device__ __forceinline__ void local_merge(uint64_t &A, uint64_t &B, int lane) {
   if constexpr (K == 128) {  // index l (key A of lane l) against index 127 - l (key B of lane 63 - l)
     const uint64_t PA = key_mirror<63>(B, lane), PB = key_mirror<63>(A, lane);
-    A = A < PA ? A : PA;
-    B = B < PB ? PB : B;
+    A = key_min(A, PA);
+    B = key_max(B, PB);
     merge_strides<32>(A, B, lane);
   } else {  // inside A and inside B: lane l against lane l ^ (K - 1)
     const uint64_t PA = key_mirror<K - 1>(A, lane), PB = key_mirror<K - 1>(B, lane);
-    const bool lower = (lane & (K / 2)) == 0;
-    A = ((A < PA) == lower) ? A : PA;
-    B = ((B < PB) == lower) ? B : PB;
+    key_stage(A, A, PA, B, B, PB, lower_lanes<K / 2>());
     if constexpr (K >= 4) merge_strides<K / 4>(A, B, lane);
   }
 }
@@ -697,7 +768,7 @@ __device__ __forceinline__ void local_merges(uint64_t &A, uint64_t &B, int lane,
   if constexpr (K < 128) local_merges<2 * K>(A, B, lane, m);
 }
 
-// Sort of keys[0, n) in LDS, ascending; keys[n, ceil(n / 128) * 128) must hold +inf (~0); n >= 1.  Barrier before (the caller's
+// Sort of keys[0, n) in LDS, ascending; keys[n, ceil(n / 128) * 128) must hold KEY_INF; n >= 1.  Barrier before (the caller's
 // stores to `keys`), barrier after.  Comparators with stride <= 64 pair keys inside one aligned 128-key chunk, and a wave holds
 // a chunk in REGISTERS (lane l: keys l and l + 64): stride 64 is in-lane, the mirrors and strides 32 / 16 use
 // v_permlane32_swap / v_permlane16_swap, the rest DPP -- an LDS round trip per stage was the latency of this kernel.  So the
@@ -723,25 +794,13 @@ __device__ __forceinline__ void lds_bitonic_sort(uint64_t *keys, int n, int tid)
     for (int i = tid; i < (nup >> 1) + half; i += 256) {  // (i enumerates (block, off) over every block that starts below nup)
       const int blk = i >> hs, off = i & (half - 1);
       const int l = (blk << (hs + 1)) + off, r = (blk << (hs + 1)) + k - 1 - off;
-      if (r < nup) {
-        const uint64_t a = keys[l], b = keys[r];
-        if (a > b) {
-          keys[l] = b;
-          keys[r] = a;
-        }
-      }
+      if (r < nup) key_minmax(keys[l], keys[r], keys[l], keys[r]);
     }
     __syncthreads();
     for (int j = k >> 2; j >= 128; j >>= 1) {  // half-cleaners through LDS
       for (int i = tid; i < (nup >> 1); i += 256) {
         const int l = ((i & ~(j - 1)) << 1) | (i & (j - 1)), r = l + j;
-        if (r < nup && ((l & ~(k - 1)) + half) < nup) {
-          const uint64_t a = keys[l], b = keys[r];
-          if (a > b) {
-            keys[l] = b;
-            keys[r] = a;
-          }
-        }
+        if (r < nup && ((l & ~(k - 1)) + half) < nup) key_minmax(keys[l], keys[r], keys[l], keys[r]);
       }
       __syncthreads();
     }
@@ -757,18 +816,14 @@ __device__ __forceinline__ void lds_bitonic_sort(uint64_t *keys, int n, int tid)
   }
 }
 
-// keys[0, T) holds a BITONIC sequence (ascending, +inf, descending: sort_long_list's merge step), T a power of two >= 128:
+// keys[0, T) holds a BITONIC sequence (ascending, KEY_INF, descending: sort_long_list's merge step), T a power of two >= 128:
 // its half-cleaners of stride T/2 ... 1 sort it.
 __device__ __forceinline__ void lds_bitonic_merge(uint64_t *keys, int T, int tid) {
   const int lane = tid & 63, wave = tid >> 6;
   for (int j = T >> 1; j >= 128; j >>= 1) {
     for (int i = tid; i < (T >> 1); i += 256) {
       const int l = ((i & ~(j - 1)) << 1) | (i & (j - 1)), r = l + j;
-      const uint64_t a = keys[l], b = keys[r];
-      if (a > b) {
-        keys[l] = b;
-        keys[r] = a;
-      }
+      key_minmax(keys[l], keys[r], keys[l], keys[r]);
     }
     __syncthreads();
   }
@@ -786,7 +841,7 @@ __device__ __forceinline__ void lds_bitonic_merge(uint64_t *keys, int T, int tid
 // rasterizer_impl.cu:353-368).  (1) chunks of T keys (ids + gathered depths) are sorted in LDS -> b; (2) merge passes b -> a -> b ... over runs of
 // T, 2T, ...: the output of a pair of runs is produced T keys at a time -- the merge-path split of every T-th output
 // diagonal is found by binary search (one thread per diagonal), the two input pieces (together T keys) are loaded as
-// [A ascending | +inf | B descending], a bitonic sequence that ONE merge level sorts.  Everything inside the tile's own
+// [A ascending | KEY_INF | B descending], a bitonic sequence that ONE merge level sorts.  Everything inside the tile's own
 // workgroup and key segment; returns the buffer that holds the sorted keys.
 __device__ const uint64_t *sort_long_list(uint64_t *lds, int T, const uint32_t *ids, const float *__restrict__ depths, uint64_t *a,
                                           uint64_t *b, int n, int tid) {
@@ -794,7 +849,7 @@ __device__ const uint64_t *sort_long_list(uint64_t *lds, int T, const uint32_t *
   for (int c0 = 0; c0 < n; c0 += T) {
     const int len = min(T, n - c0);
     for (int i = tid; i < T; i += 256) {
-      uint64_t key = ~0ull;
+      uint64_t key = KEY_INF;
       if (i < len) {
         const uint32_t id = ids[c0 + i];
         key = ((uint64_t)__float_as_uint(depths[id]) << 32) | id;
@@ -837,7 +892,7 @@ __device__ const uint64_t *sort_long_list(uint64_t *lds, int T, const uint32_t *
           const int a0 = (int)split_s[j - j0], a1 = (int)split_s[j - j0 + 1];
           const int d0 = j * T, d1 = min(tot, d0 + T);
           const int b0 = d0 - a0, cA = a1 - a0, cB = (d1 - a1) - b0;
-          for (int i = tid; i < T; i += 256) lds[i] = i < cA ? A[a0 + i] : (i >= T - cB ? B[b0 + (T - 1 - i)] : ~0ull);
+          for (int i = tid; i < T; i += 256) lds[i] = i < cA ? A[a0 + i] : (i >= T - cB ? B[b0 + (T - 1 - i)] : KEY_INF);
           __syncthreads();
           lds_bitonic_merge(lds, T, tid);
           for (int i = tid; i < cA + cB; i += 256) D[d0 + i] = lds[i];
@@ -903,9 +958,9 @@ __global__ __launch_bounds__(256) void k_tile_sort(ImageWS im, const float *__re
     if (pass == 1 && 2 * m <= cap) return;  // pass 2's
     if (pass == 2 && m > cap) return;       // pass 1's (here cap = half of pass 1's)
     // the tile's ids as scattered (point_list, sorted in place below) + their depths gathered from the 4-byte depth array (L2)
-    const int nup = ((n + 127) >> 7) << 7;  // (+inf up to the end of the last 128-key chunk: lds_bitonic_sort)
+    const int nup = ((n + 127) >> 7) << 7;  // (KEY_INF up to the end of the last 128-key chunk: lds_bitonic_sort)
     for (int i = tid; i < nup; i += 256) {
-      uint64_t key = ~0ull;
+      uint64_t key = KEY_INF;
       if (i < n) {
         const uint32_t id = point_list[beg + i];
         key = ((uint64_t)__float_as_uint(depths[id]) << 32) | id;

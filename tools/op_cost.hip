@@ -21,6 +21,7 @@ __global__ void k(float *out, float a, float b) {
   unsigned addr_l = threadIdx.x * 16;                  // lane-distinct 16-B reads
   unsigned long long m = 0x5555555555555555ull;
   int si = 0;
+  double d2 = 1.0 + threadIdx.x, e2 = 2.0 + threadIdx.x, e3 = 3.5;
   for (int i = 0; i < ITERS; i++) {
     if (MODE == 0) asm volatile(REP8("v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %3, %3, %1, %2\n") : "+v"(x0) : "v"(a), "v"(b), "v"(x1));
     if (MODE == 1) asm volatile(REP8("v_cmp_gt_f32_e64 s[20:21], %0, %1\n v_cmp_lt_f32_e64 s[22:23], %0, %2\n") : : "v"(x0), "v"(a), "v"(b) : "s20", "s21", "s22", "s23");
@@ -50,6 +51,10 @@ __global__ void k(float *out, float a, float b) {
     if (MODE == 25) asm volatile(REP8("v_cmp_gt_f32_e64 s[20:21], %0, %1\n s_and_b64 s[22:23], s[20:21], %2\n") : : "v"(x0), "v"(a), "s"(m) : "s20", "s21", "s22", "s23", "scc");
     if (MODE == 26) asm volatile(REP8("v_add_u32 %0, %0, %1\n v_lshlrev_b32 %2, 1, %2\n") : "+v"(u.x) : "v"(u.y), "v"(u.y));
     if (MODE == 27) asm volatile(REP8("v_mul_f32 %0, 0x3fb8aa3b, %0\n v_mul_f32 %1, 0x3fb8aa3b, %1\n") : "+v"(x0), "+v"(x1));
+    if (MODE == 29) asm volatile(REP8("v_cmp_lt_u64_e64 s[20:21], %0, %1\n v_cmp_gt_u64_e64 s[22:23], %0, %1\n") : : "v"(d2), "v"(e2) : "s20", "s21", "s22", "s23");
+    if (MODE == 30) asm volatile(REP8("v_min_f64 %0, %0, %1\n v_max_f64 %2, %2, %1\n") : "+v"(d2), "+v"(e2) : "v"(e3));
+    if (MODE == 31) asm volatile(REP8("v_cmp_lt_f64_e64 s[20:21], %0, %1\n v_cmp_gt_f64_e64 s[22:23], %0, %1\n") : : "v"(d2), "v"(e2) : "s20", "s21", "s22", "s23");
+    if (MODE == 32) asm volatile(REP8("v_mov_b64 %0, %1\n v_mov_b64 %2, %1\n") : "=v"(d2), "+v"(e3), "=v"(e2));
     if (MODE == 28) asm volatile(REP8("v_mov_b32_dpp %0, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n") : "+v"(x0) : "v"(x1));
   }
   out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + q.x + q.y + q.z + q.w + si + p.x + p.y + u.x;
@@ -104,5 +109,9 @@ int main() {
   run<26>("v_add_u32 / v_lshlrev_b32", d);
   run<27>("v_mul_f32 with literal", d);
   run<28>("v_mov_b32_dpp row_bcast / row_shr", d);
+  run<29>("v_cmp_lt_u64 / v_cmp_gt_u64 -> SGPR pair", d);
+  run<30>("v_min_f64 / v_max_f64", d);
+  run<31>("v_cmp_lt_f64 / v_cmp_gt_f64 -> SGPR pair", d);
+  run<32>("v_mov_b64", d);
   return 0;
 }
