@@ -619,25 +619,25 @@ __device__ __forceinline__ uint32_t lane_xor(uint32_t x, int lane) {
     const gsaj_u32x2 r = __builtin_amdgcn_permlane16_swap(x, x, false, false);  // r[0] = rows [0,0,2,2], r[1] = rows [1,1,3,3]
     return (lane & 16) ? r[0] : r[1];
   } else if (J == 8) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xF, 0xF, false);  // row_ror:8
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x128, 0xF, 0xF, true);  // row_ror:8 (every lane reads a lane: no `old` value to initialise)
   } else if (J == 4) {
-    int t = __builtin_amdgcn_update_dpp(0, (int)x, 0x104, 0xF, 0x5, false);          // row_shl:4 -> banks 0, 2 (lane <- lane + 4)
+    int t = __builtin_amdgcn_mov_dpp((int)x, 0x104, 0xF, 0x5, false);                  // row_shl:4 -> banks 0, 2 (lane <- lane + 4); banks 1, 3: next line
     t = __builtin_amdgcn_update_dpp(t, (int)x, 0x114, 0xF, 0xA, false);              // row_shr:4 -> banks 1, 3 (lane <- lane - 4)
     return (uint32_t)t;
   } else if (J == 2) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
   } else {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
   }
 }
 // value of lane (l ^ MASK) for MASK = 2^j - 1: the mirror inside groups of 2, 4, 8, 16, 32, 64 lanes (DPP quad_perm /
 // row_half_mirror / row_mirror, + the half-row / half-wave swaps above)
 template <int MASK>
 __device__ __forceinline__ uint32_t lane_mirror(uint32_t x, int lane) {
-  if (MASK == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);         // quad_perm [1,0,3,2]
-  else if (MASK == 3) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x1B, 0xF, 0xF, false);    // quad_perm [3,2,1,0]
-  else if (MASK == 7) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, false);   // row_half_mirror
-  else if (MASK == 15) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xF, 0xF, false);  // row_mirror
+  if (MASK == 1) return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true);         // quad_perm [1,0,3,2]
+  else if (MASK == 3) return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x1B, 0xF, 0xF, true);    // quad_perm [3,2,1,0]
+  else if (MASK == 7) return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x141, 0xF, 0xF, true);   // row_half_mirror
+  else if (MASK == 15) return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x140, 0xF, 0xF, true);  // row_mirror
   else if (MASK == 31) return lane_xor<16>(lane_mirror<15>(x, lane), lane);
   else return lane_xor<32>(lane_mirror<31>(x, lane), lane);
 }
