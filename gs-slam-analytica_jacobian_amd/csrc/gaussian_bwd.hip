@@ -630,6 +630,8 @@ __global__ __launch_bounds__(256) void k_gather_sums(int P, const int *__restric
         fl_a = fl_b;
         fl_b = flags_of(base + 192);
       }
+      // a group none of whose rows was reached adds nothing (opaque scenes: most groups of the Gaussians that lie behind)
+      if (__builtin_amdgcn_ballot_w64(ok) == 0ull) continue;
       // owner of row r = number of owners whose end slot is <= r (end slots are non-decreasing): binary search by shuffles
       int own = 0;
 #pragma unroll
