@@ -774,12 +774,13 @@ __device__ __forceinline__ void local_merges(uint64_t &A, uint64_t &B, int lane,
 // v_permlane32_swap / v_permlane16_swap, the rest DPP -- an LDS round trip per stage was the latency of this kernel.  So the
 // chunk sorts (merges up to 128) never touch LDS, and a merge of size k >= 256 goes through LDS only for its flip and its
 // strides >= 128 (workgroup barriers), followed by the seven chunk-local stages in registers again.
+template <int NT>
 __device__ __forceinline__ void lds_bitonic_sort(uint64_t *keys, int n, int tid) {
   const int lane = tid & 63, wave = tid >> 6;
   const int nch = (n + 127) >> 7, nup = nch << 7;  // chunks with at least one key; everything at or past nup is padding nobody reads
   int m = 2;
   while (m < n) m <<= 1;
-  for (int chunk = wave; chunk < nch; chunk += 4) {
+  for (int chunk = wave; chunk < nch; chunk += NT / 64) {
     const int ia = chunk * 128 + lane, ib = ia + 64;
     uint64_t A = keys[ia], B = keys[ib];
     local_merges<2>(A, B, lane, m);
@@ -791,20 +792,20 @@ __device__ __forceinline__ void lds_bitonic_sort(uint64_t *keys, int n, int tid)
     // blocks of k keys whose upper half holds a key: [base, base + k) with base + k / 2 < nup.  The others are sorted already.
     const int half = k >> 1;  // = 1 << hs
     // flip: base + off against base + k - 1 - off
-    for (int i = tid; i < (nup >> 1) + half; i += 256) {  // (i enumerates (block, off) over every block that starts below nup)
+    for (int i = tid; i < (nup >> 1) + half; i += NT) {  // (i enumerates (block, off) over every block that starts below nup)
       const int blk = i >> hs, off = i & (half - 1);
       const int l = (blk << (hs + 1)) + off, r = (blk << (hs + 1)) + k - 1 - off;
       if (r < nup) key_minmax(keys[l], keys[r], keys[l], keys[r]);
     }
     __syncthreads();
     for (int j = k >> 2; j >= 128; j >>= 1) {  // half-cleaners through LDS
-      for (int i = tid; i < (nup >> 1); i += 256) {
+      for (int i = tid; i < (nup >> 1); i += NT) {
         const int l = ((i & ~(j - 1)) << 1) | (i & (j - 1)), r = l + j;
         if (r < nup && ((l & ~(k - 1)) + half) < nup) key_minmax(keys[l], keys[r], keys[l], keys[r]);
       }
       __syncthreads();
     }
-    for (int chunk = wave; chunk < nch; chunk += 4) {
+    for (int chunk = wave; chunk < nch; chunk += NT / 64) {
       if (((chunk * 128) & ~(k - 1)) + half >= nup) continue;  // (its block's upper half is padding)
       const int ia = chunk * 128 + lane, ib = ia + 64;
       uint64_t A = keys[ia], B = keys[ib];
@@ -818,16 +819,17 @@ __device__ __forceinline__ void lds_bitonic_sort(uint64_t *keys, int n, int tid)
 
 // keys[0, T) holds a BITONIC sequence (ascending, KEY_INF, descending: sort_long_list's merge step), T a power of two >= 128:
 // its half-cleaners of stride T/2 ... 1 sort it.
+template <int NT>
 __device__ __forceinline__ void lds_bitonic_merge(uint64_t *keys, int T, int tid) {
   const int lane = tid & 63, wave = tid >> 6;
   for (int j = T >> 1; j >= 128; j >>= 1) {
-    for (int i = tid; i < (T >> 1); i += 256) {
+    for (int i = tid; i < (T >> 1); i += NT) {
       const int l = ((i & ~(j - 1)) << 1) | (i & (j - 1)), r = l + j;
       key_minmax(keys[l], keys[r], keys[l], keys[r]);
     }
     __syncthreads();
   }
-  for (int chunk = wave; chunk * 128 < T; chunk += 4) {
+  for (int chunk = wave; chunk * 128 < T; chunk += NT / 64) {
     const int ia = chunk * 128 + lane, ib = ia + 64;
     uint64_t A = keys[ia], B = keys[ib];
     merge_strides<64>(A, B, lane);
@@ -843,12 +845,14 @@ __device__ __forceinline__ void lds_bitonic_merge(uint64_t *keys, int T, int tid
 // diagonal is found by binary search (one thread per diagonal), the two input pieces (together T keys) are loaded as
 // [A ascending | KEY_INF | B descending], a bitonic sequence that ONE merge level sorts.  Everything inside the tile's own
 // workgroup and key segment; returns the buffer that holds the sorted keys.
-__device__ const uint64_t *sort_long_list(uint64_t *lds, int T, const uint32_t *ids, const float *__restrict__ depths, uint64_t *a,
-                                          uint64_t *b, int n, int tid) {
-  __shared__ uint32_t split_s[PRE_BLOCK + 1];
+// (split_s: PRE_BLOCK + 1 words of the kernel's DYNAMIC LDS behind the T keys -- as a static array it sat beside every workgroup's 32 KB
+// of keys, also those of ordinary lists, and kept the fifth workgroup off a CU.)
+template <int NT>
+__device__ const uint64_t *sort_long_list(uint64_t *lds, int T, uint32_t *split_s, const uint32_t *ids, const float *__restrict__ depths,
+                                          uint64_t *a, uint64_t *b, int n, int tid) {
   for (int c0 = 0; c0 < n; c0 += T) {
     const int len = min(T, n - c0);
-    for (int i = tid; i < T; i += 256) {
+    for (int i = tid; i < T; i += NT) {
       uint64_t key = KEY_INF;
       if (i < len) {
         const uint32_t id = ids[c0 + i];
@@ -857,8 +861,8 @@ __device__ const uint64_t *sort_long_list(uint64_t *lds, int T, const uint32_t *
       lds[i] = key;
     }
     __syncthreads();
-    lds_bitonic_sort(lds, T, tid);
-    for (int i = tid; i < len; i += 256) b[c0 + i] = lds[i];
+    lds_bitonic_sort<NT>(lds, T, tid);
+    for (int i = tid; i < len; i += NT) b[c0 + i] = lds[i];
     __syncthreads();
   }
   uint64_t *src = b, *dst = a;
@@ -871,12 +875,12 @@ __device__ const uint64_t *sort_long_list(uint64_t *lds, int T, const uint32_t *
       const uint64_t *A = src + p0, *B = src + p0 + width;
       uint64_t *D = dst + p0;
       if (lb == 0) {
-        for (int i = tid; i < la; i += 256) D[i] = A[i];
+        for (int i = tid; i < la; i += NT) D[i] = A[i];
         continue;
       }
       const int tot = la + lb, nblk = (tot + T - 1) / T;
       for (int j0 = 0; j0 < nblk; j0 += PRE_BLOCK) {
-        for (int t = tid; t <= PRE_BLOCK; t += 256) {  // merge-path split of diagonal d: how many of the first d outputs come from A
+        for (int t = tid; t <= PRE_BLOCK; t += NT) {  // merge-path split of diagonal d: how many of the first d outputs come from A
           const long long dl = (long long)(j0 + t) * T;
           const int d = (int)min(dl, (long long)tot);
           int lo = max(0, d - lb), hi = min(d, la);
@@ -892,10 +896,10 @@ __device__ const uint64_t *sort_long_list(uint64_t *lds, int T, const uint32_t *
           const int a0 = (int)split_s[j - j0], a1 = (int)split_s[j - j0 + 1];
           const int d0 = j * T, d1 = min(tot, d0 + T);
           const int b0 = d0 - a0, cA = a1 - a0, cB = (d1 - a1) - b0;
-          for (int i = tid; i < T; i += 256) lds[i] = i < cA ? A[a0 + i] : (i >= T - cB ? B[b0 + (T - 1 - i)] : KEY_INF);
+          for (int i = tid; i < T; i += NT) lds[i] = i < cA ? A[a0 + i] : (i >= T - cB ? B[b0 + (T - 1 - i)] : KEY_INF);
           __syncthreads();
-          lds_bitonic_merge(lds, T, tid);
-          for (int i = tid; i < cA + cB; i += 256) D[d0 + i] = lds[i];
+          lds_bitonic_merge<NT>(lds, T, tid);
+          for (int i = tid; i < cA + cB; i += NT) D[d0 + i] = lds[i];
           __syncthreads();
         }
       }
@@ -913,7 +917,11 @@ __device__ const uint64_t *sort_long_list(uint64_t *lds, int T, const uint32_t *
 // range (cub::DeviceRadixSort + identifyTileRanges, rasterizer_impl.cu:353-368, 116-138); the tile's `reached` flags cleared.
 GSAJ_TRACE_DEFINE(sort)
 
-__global__ __launch_bounds__(256) void k_tile_sort(ImageWS im, const float *__restrict__ depths, uint64_t *__restrict__ inst_key,
+// NT threads per tile: 256, or 512 from 4096 keys of LDS on -- 32 KB and more per workgroup limit a CU to four or five of them, and
+// with four waves each the kernel (dependent LDS round trips between barriers) had 16-20 waves per CU to hide them behind (cfg5:
+// 1.66 -> 1.48 ms; at 2048 keys a CU already holds its 32 waves and 512 threads only idle: cfg3 294 -> 389 us, so not there)
+template <int NT>
+__global__ __launch_bounds__(NT) void k_tile_sort(ImageWS im, const float *__restrict__ depths, uint64_t *__restrict__ inst_key,
                                                    uint64_t *__restrict__ keys_b, uint32_t *point_list,
                                                    uint8_t *__restrict__ reached, int cap, int pass, int rec16, ViewStrides vs) {
   {
@@ -945,13 +953,16 @@ __global__ __launch_bounds__(256) void k_tile_sort(ImageWS im, const float *__re
     if (tid == 0 && tile == 0) im.counters[7] = (uint32_t)rec16;  // row format of this frame (read by the compositors)
     // no pixel has reached any of the tile's instances yet (the reverse compositor sets the flags of the rows it writes).  The
     // flags are indexed by emission slot, not by sorted position: the tiles' ranges merely tile [0, R)
-    for (uint32_t k = beg + tid; k < end; k += 256) reached[k] = 0;
+    for (uint32_t k = beg + tid; k < end; k += NT) reached[k] = 0;
   }
   if (n == 0) return;
   const uint64_t *sorted = keys;
   if (n > cap) {
     if (pass == 2) return;  // (pass 2 has half of pass 1's LDS: pass 1 took it)
-    sorted = sort_long_list(keys, cap, point_list + beg, depths, inst_key + beg, keys_b + beg, n, tid);
+    // chunks of `cap` keys with the merge-path splits behind them; from 4096 keys on (all of a CU's LDS for five workgroups) the
+    // chunk is half the capacity and the splits sit in the other half
+    const int T = cap >= 4096 ? cap / 2 : cap;
+    sorted = sort_long_list<NT>(keys, T, reinterpret_cast<uint32_t *>(keys + T), point_list + beg, depths, inst_key + beg, keys_b + beg, n, tid);
   } else {
     int m = 2;
     while (m < n) m <<= 1;
@@ -959,7 +970,7 @@ __global__ __launch_bounds__(256) void k_tile_sort(ImageWS im, const float *__re
     if (pass == 2 && m > cap) return;       // pass 1's (here cap = half of pass 1's)
     // the tile's ids as scattered (point_list, sorted in place below) + their depths gathered from the 4-byte depth array (L2)
     const int nup = ((n + 127) >> 7) << 7;  // (KEY_INF up to the end of the last 128-key chunk: lds_bitonic_sort)
-    for (int i = tid; i < nup; i += 256) {
+    for (int i = tid; i < nup; i += NT) {
       uint64_t key = KEY_INF;
       if (i < n) {
         const uint32_t id = point_list[beg + i];
@@ -971,16 +982,16 @@ __global__ __launch_bounds__(256) void k_tile_sort(ImageWS im, const float *__re
 #ifdef GSAJ_BLOCK_TRACE
     tr_b = wall_clock64();
 #endif
-    lds_bitonic_sort(keys, n, tid);
+    lds_bitonic_sort<NT>(keys, n, tid);
   }
 #ifdef GSAJ_BLOCK_TRACE
   tr_c = wall_clock64();
 #endif
-  for (int i = tid; i < n; i += 256) point_list[beg + (uint32_t)i] = (uint32_t)sorted[i];
+  for (int i = tid; i < n; i += NT) point_list[beg + (uint32_t)i] = (uint32_t)sorted[i];
   GSAJ_TRACE_END(sort)
 #ifdef GSAJ_BLOCK_TRACE
   if ((threadIdx.x & 63) == 0) {
-    unsigned long long *t = g_trace_sort + 4 * (blockIdx.x * 4 + (threadIdx.x >> 6));
+    unsigned long long *t = g_trace_sort + 4 * (blockIdx.x * (NT / 64) + (threadIdx.x >> 6));
     t[2] = tr_b - tr_a;
     t[3] = tr_c - tr_b;
   }
@@ -1059,16 +1070,25 @@ int launch_tile_binning(int P, int sort_cap, int rec16, int grid_x, int grid_y, 
     int cap = 128;
     while (cap < sort_cap && cap < SORT_CAP) cap <<= 1;
     if (sizeof(uint64_t) * (size_t)cap > 65536)  // lists of 8193 .. 16384 keys: more dynamic LDS than the 64 KB default limit
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_sort), hipFuncAttributeMaxDynamicSharedMemorySize,
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tile_sort<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(sizeof(uint64_t) * (size_t)cap));
-    if (cap >= 4096) {
-      hipLaunchKernelGGL(k_tile_sort, dim3(grid_x * grid_y, views), dim3(256), sizeof(uint64_t) * (size_t)cap, s, im, g.depths,
-                         b.keys_unsorted, b.keys, b.point_list, b.reached, cap, 1, rec16, vs);
-      hipLaunchKernelGGL(k_tile_sort, dim3(grid_x * grid_y, views), dim3(256), sizeof(uint64_t) * (size_t)(cap / 2), s, im, g.depths,
-                         b.keys_unsorted, b.keys, b.point_list, b.reached, cap / 2, 2, rec16, vs);
+    // (+ the merge-path splits of a list longer than the capacity: behind the keys below 4096, inside the capacity from there on)
+    const size_t split_bytes = cap >= 4096 ? 0 : sizeof(uint32_t) * (PRE_BLOCK + 1);
+    // a launch with 32 KB of keys or more per workgroup runs 512 threads per tile (k_tile_sort)
+    auto launch = [&](int lds_keys, int pass, size_t extra) {
+      const size_t dyn = sizeof(uint64_t) * (size_t)lds_keys + extra;
+      if (lds_keys >= 4096)
+        hipLaunchKernelGGL(k_tile_sort<512>, dim3(grid_x * grid_y, views), dim3(512), dyn, s, im, g.depths, b.keys_unsorted, b.keys,
+                           b.point_list, b.reached, lds_keys, pass, rec16, vs);
+      else
+        hipLaunchKernelGGL(k_tile_sort<256>, dim3(grid_x * grid_y, views), dim3(256), dyn, s, im, g.depths, b.keys_unsorted, b.keys,
+                           b.point_list, b.reached, lds_keys, pass, rec16, vs);
+    };
+    if (cap >= 4096) {  // two launches by padded list length: the many lists below half the capacity run with half the LDS
+      launch(cap, 1, 0);
+      launch(cap / 2, 2, 0);
     } else {
-      hipLaunchKernelGGL(k_tile_sort, dim3(grid_x * grid_y, views), dim3(256), sizeof(uint64_t) * (size_t)cap, s, im, g.depths,
-                         b.keys_unsorted, b.keys, b.point_list, b.reached, cap, 0, rec16, vs);
+      launch(cap, 0, split_bytes);
     }
   }
   GSAJ_HIP_CHECK(hipGetLastError());
