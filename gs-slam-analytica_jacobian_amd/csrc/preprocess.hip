@@ -920,6 +920,10 @@ GSAJ_TRACE_DEFINE(sort)
 // NT threads per tile: 256, or 512 from 4096 keys of LDS on -- 32 KB and more per workgroup limit a CU to four or five of them, and
 // with four waves each the kernel (dependent LDS round trips between barriers) had 16-20 waves per CU to hide them behind (cfg5:
 // 1.66 -> 1.48 ms; at 2048 keys a CU already holds its 32 waves and 512 threads only idle: cfg3 294 -> 389 us, so not there)
+#ifndef GSAJ_SORT_128_MAX
+#define GSAJ_SORT_128_MAX 1024  // LDS capacity (keys) up to which a tile is sorted by 128 threads: lists of a few hundred keys are two or three
+                                 // 128-key chunks, and of four waves one or two only waited at the barriers (cfg2 47 -> 43 us; one wave: 46)
+#endif
 template <int NT>
 __global__ __launch_bounds__(NT) void k_tile_sort(ImageWS im, const float *__restrict__ depths, uint64_t *__restrict__ inst_key,
                                                    uint64_t *__restrict__ keys_b, uint32_t *point_list,
@@ -1080,8 +1084,11 @@ int launch_tile_binning(int P, int sort_cap, int rec16, int grid_x, int grid_y, 
       if (lds_keys >= 4096)
         hipLaunchKernelGGL(k_tile_sort<512>, dim3(grid_x * grid_y, views), dim3(512), dyn, s, im, g.depths, b.keys_unsorted, b.keys,
                            b.point_list, b.reached, lds_keys, pass, rec16, vs);
-      else
+      else if (lds_keys > GSAJ_SORT_128_MAX)
         hipLaunchKernelGGL(k_tile_sort<256>, dim3(grid_x * grid_y, views), dim3(256), dyn, s, im, g.depths, b.keys_unsorted, b.keys,
+                           b.point_list, b.reached, lds_keys, pass, rec16, vs);
+      else
+        hipLaunchKernelGGL(k_tile_sort<128>, dim3(grid_x * grid_y, views), dim3(128), dyn, s, im, g.depths, b.keys_unsorted, b.keys,
                            b.point_list, b.reached, lds_keys, pass, rec16, vs);
     };
     if (cap >= 4096) {  // two launches by padded list length: the many lists below half the capacity run with half the LDS
