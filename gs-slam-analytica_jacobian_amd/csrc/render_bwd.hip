@@ -29,14 +29,17 @@
 //  Gaussian's rows in a fixed order, so gradients are bit-reproducible run to run (the reference's
 //  float atomics are not).  Entries beyond the quadrant's / tile's furthest last-contributor are
 //  never visited -- not even fetched: the list is a list of Gaussian ids, and the 48-byte rows they name
-//  (GeomWS.splat) are gathered per round of 48 entries, ids one round ahead.  Rows beyond the tile's furthest
+//  (GeomWS.splat) are gathered per round of 48 entries -- one 16-byte piece per wave and entry, a round ahead of their use, the
+//  ids two rounds ahead (see the staging below).  Rows beyond the tile's furthest
 //  last contributor keep the one-byte `reached = 0` flag the tile sort gave them instead of a zero row.
 //  Workgroups take tiles longest list first (ImageWS.tile_order, written by the preprocess kernel's frame scan).
 #include "gsaj_common.h"
 #include "loss_terms.h"
 #include "wave_reduce.h"
 
-#define BWD_ROUND 48   // list entries staged per workgroup round: 30.8 KB LDS + 96 VGPRs = five resident workgroups per CU (all 1200 tiles of a 640x480 frame at once)
+#define BWD_ROUND 48   // list entries staged per workgroup round: 31.1 KB LDS + 96 VGPRs = five resident workgroups per CU (all 1200 tiles of a 640x480
+                       // frame at once).  56 (with ACC_STRIDE 56: 32.6 KB) measured 460 against 426-445 us; 64 needs cheaper accumulators, and
+                       // sharing them by wave pairs through ds_add_f32 measured 520 us (an LDS float atomic costs hundreds of cycles)
 #define SLOTS 8        // accepted entries per phase-2 batch
 #define WU_STRIDE 65   // float2 per slot row (64 pixels + 1: conflict-free ds_read_b64 in phase 2)
 #define ACC_C 10       // partials per (entry, wave)

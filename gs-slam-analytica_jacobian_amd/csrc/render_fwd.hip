@@ -109,7 +109,7 @@ __global__ __launch_bounds__(GSAJ_FWD_THREADS) __attribute__((amdgpu_waves_per_e
   v2f Crg = {0.f, 0.f}, Cbd = {0.f, 0.f};
   const v2f px2 = {pxf, pxf}, py2 = {pyf, pyf};
   auto composite2 = [&](const float4 p0, const float4 p1, const float4 p2, const float4 cA, const float4 cB, const float2 pos,
-                        float &tA, float &tB, bool &okA, bool &okB) {
+                        float &T_afterA) {
     const v2f dx = v2f{p0.x, p0.y} - px2, dy = v2f{p0.z, p0.w} - py2;
     const v2f t = v2f{p1.z, p1.w} * dy;
     const v2f u = v2f{p2.x, p2.y} * dy;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(GSAJ_FWD_THREADS) __attribute__((amdgpu_waves_per_e
     {
       const float alpha0 = fminf(0.99f, oe.x);
       bool ok = !done && pw.x <= 0.0f && alpha0 >= (1.0f / 255.0f);
-      tA = __builtin_fmaf(-alpha0, T, T);
+      const float tA = __builtin_fmaf(-alpha0, T, T);
       const bool sat = ok && tA < 0.0001f;  // this pixel is saturated: stop before this entry
       done = done || sat;
       ok = ok && !sat;
@@ -128,12 +128,12 @@ __global__ __launch_bounds__(GSAJ_FWD_THREADS) __attribute__((amdgpu_waves_per_e
       Cbd = __builtin_elementwise_fma(v2f{cA.z, cA.w}, w2, Cbd);
       T = ok ? tA : T;
       last = ok ? __float_as_uint(pos.x) : last;
-      okA = ok;
+      T_afterA = T;
     }
     {
       const float alpha0 = fminf(0.99f, oe.y);
       bool ok = !done && pw.y <= 0.0f && alpha0 >= (1.0f / 255.0f);
-      tB = __builtin_fmaf(-alpha0, T, T);
+      const float tB = __builtin_fmaf(-alpha0, T, T);
       const bool sat = ok && tB < 0.0001f;
       done = done || sat;
       ok = ok && !sat;
@@ -143,7 +143,6 @@ __global__ __launch_bounds__(GSAJ_FWD_THREADS) __attribute__((amdgpu_waves_per_e
       Cbd = __builtin_elementwise_fma(v2f{cB.z, cB.w}, w2, Cbd);
       T = ok ? tB : T;
       last = ok ? __float_as_uint(pos.y) : last;
-      okB = ok;
     }
   };
 
@@ -207,28 +206,35 @@ __global__ __launch_bounds__(GSAJ_FWD_THREADS) __attribute__((amdgpu_waves_per_e
         const float4 c0 = rec[pb + 6], c1 = rec[pb + 7], c2 = rec[pb + 8], c3 = rec[pb + 9], c4 = rec[pb + 10];
         const float2 c5 = rec2[(pb + 11) * 2];
         uint32_t pack = 0u;  // (scalar)
+        // "touched" (forward.cu:512-514): the pixel took the entry and is left with T > 0.5.  A pixel that takes an entry leaves
+        // with a strictly smaller T (alpha >= 1/255), one that does not keeps its T: "took it" is T_after < T_before -- two
+        // compares on registers, and T_after > 0.5 of the second entry is the "anyone still counting" test as well (a ballot of the
+        // accept flag itself -- or of any `a && b` -- is first materialised as 0 / 1 and compared again; the AND of two ballots of plain
+        // compares is two v_cmp and a scalar AND).
         {
-          float tA, tB;
-          bool okA, okB;
-          composite2(a0, a1, a2, a3, a4, a5, tA, tB, okA, okB);
+          const float T0 = T;
+          float Ta;
+          composite2(a0, a1, a2, a3, a4, a5, Ta);
           if (counting) {
-            const uint32_t nA = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(okA && tA > 0.5f));
-            const uint32_t nB = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(okB && tB > 0.5f));
+            const unsigned long long hB = __builtin_amdgcn_ballot_w64(T > 0.5f);
+            const uint32_t nA = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(Ta > 0.5f) & __builtin_amdgcn_ballot_w64(Ta < T0));
+            const uint32_t nB = (uint32_t)__popcll(hB & __builtin_amdgcn_ballot_w64(T < Ta));
             pack = nA | (nB << 8);
-            counting = __builtin_amdgcn_ballot_w64(T > 0.5f) != 0ull;
+            counting = hB != 0ull;
           }
         }
         a0 = rec[pb + 12], a1 = rec[pb + 13], a2 = rec[pb + 14], a3 = rec[pb + 15], a4 = rec[pb + 16];
         a5 = rec2[(pb + 17) * 2];
         {
-          float tC, tD;
-          bool okC, okD;
-          composite2(c0, c1, c2, c3, c4, c5, tC, tD, okC, okD);
+          const float T0 = T;
+          float Tc;
+          composite2(c0, c1, c2, c3, c4, c5, Tc);
           if (counting) {
-            const uint32_t nC = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(okC && tC > 0.5f));
-            const uint32_t nD = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(okD && tD > 0.5f));
+            const unsigned long long hD = __builtin_amdgcn_ballot_w64(T > 0.5f);
+            const uint32_t nC = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(Tc > 0.5f) & __builtin_amdgcn_ballot_w64(Tc < T0));
+            const uint32_t nD = (uint32_t)__popcll(hD & __builtin_amdgcn_ballot_w64(T < Tc));
             pack |= (nC << 16) | (nD << 24);
-            counting = __builtin_amdgcn_ballot_w64(T > 0.5f) != 0ull;
+            counting = hD != 0ull;
           }
         }
         cnt4 = ((lane >> 2) == (i >> 2)) ? pack : cnt4;
