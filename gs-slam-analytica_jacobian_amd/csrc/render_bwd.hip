@@ -315,26 +315,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
       if (todo != 0ull) {
         int jj = 63 - __builtin_clzll(todo);
         todo &= ~(1ull << jj);
-        float4 n0 = rec[jj * REC_F4 + 0], n1 = rec[jj * REC_F4 + 1], n2 = rec[jj * REC_F4 + 2];
+        // the row of the entry being worked on: q01 = (mean x, mean y), k = (pre-scaled conic, opacity), c = (r, g, b, depth).  The NEXT
+        // entry's row is requested into the SAME registers as soon as the current values have had their last use -- (mean, conic)
+        // after the power, the colour after c . g -- so no copies rotate a pipeline, and the LDS round trip still hides behind the
+        // rest of the entry's arithmetic
+        float2 q01 = reinterpret_cast<const float2 *>(rec)[jj * (REC_F4 * 2)];
+        float4 k = rec[jj * REC_F4 + 1], c = rec[jj * REC_F4 + 2];
         while (true) {
           const int j = jj;
           const uint32_t idx = first_idx + (uint32_t)j;
-          const float4 r0 = n0, r1 = n1, r2 = n2;
           const bool more = todo != 0ull;
-          if (more) {  // software pipeline: request the next record before working on this one
+          if (more) {
             jj = 63 - __builtin_clzll(todo);
             todo &= ~(1ull << jj);
-            n0 = rec[jj * REC_F4 + 0];
-            n1 = rec[jj * REC_F4 + 1];
-            n2 = rec[jj * REC_F4 + 2];
           }
-          const float dx = r0.x - pxf, dy = r0.y - pyf;
+          const float dx = q01.x - pxf, dy = q01.y - pyf;
           // the forward's own expression (gsaj_common.h): both passes decide power <= 0 / alpha >= 1/255 on identical bits
-          const float p2 = gsaj_power2(dx, dy, r1.x, r1.y, r1.z);
-          const float oG = r1.w * __builtin_amdgcn_exp2f(p2);  // opacity x G
+          const float p2 = gsaj_power2(dx, dy, k.x, k.y, k.z);
+          const float oG = k.w * __builtin_amdgcn_exp2f(p2);  // opacity x G
+          // (unconditional: after the last entry the same row is read once more -- a load under `if (more)` would merge with the old
+          // value through register copies)
+          q01 = reinterpret_cast<const float2 *>(rec)[jj * (REC_F4 * 2)];
+          k = rec[jj * REC_F4 + 1];
           // alpha = min(0.99, o G) >= 1/255  <=>  o G >= 1/255: the clamp is applied after the mask (one select fewer); the
           // decision is the forward's bit for bit
           const bool valid = idx < last && p2 <= 0.0f && oG >= (1.0f / 255.0f);
+          const float cg = c.x * gC0 + c.y * gC1 + c.z * gC2 + c.w * gD;
+          c = rec[jj * REC_F4 + 2];
           if (__builtin_amdgcn_ballot_w64(valid) != 0ull) {
             // a lane that skips this entry runs the same arithmetic with alpha = 0: T and the recurrence come out unchanged
             // and (w, u) = 0
@@ -348,7 +355,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
             // (backward.cu:799-823, colour and depth alike): the four recurrences accum_rec <- alpha c + (1 - alpha) accum_rec
             // collapse into ONE for the scalar s = accum_rec . g, s <- s + alpha (c . g - s) -- 6 VALU operations per entry
             // instead of 12, same value up to fp32 rounding (the dot product is linear in accum_rec)
-            const float cg = r2.x * gC0 + r2.y * gC1 + r2.z * gC2 + r2.w * gD;
             const float dd = cg - accS;
             const float dL_dalpha = dd * T - Tf_bg * inv1ma;
             accS += alpha * dd;
