@@ -340,7 +340,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
           // alpha = min(0.99, o G) >= 1/255  <=>  o G >= 1/255: the clamp is applied after the mask (one select fewer); the
           // decision is the forward's bit for bit
           const bool valid = idx < last && p2 <= 0.0f && oG >= (1.0f / 255.0f);
-          const float cg = c.x * gC0 + c.y * gC1 + c.z * gC2 + c.w * gD;
+          float cg = c.x * gC0 + c.y * gC1 + c.z * gC2 + c.w * gD;
+          asm volatile("" : "+v"(cg));  // (c . g is formed HERE, not sunk into the branch below: the colour registers are free for the next row)
           c = rec[jj * REC_F4 + 2];
           if (__builtin_amdgcn_ballot_w64(valid) != 0ull) {
             // a lane that skips this entry runs the same arithmetic with alpha = 0: T and the recurrence come out unchanged
