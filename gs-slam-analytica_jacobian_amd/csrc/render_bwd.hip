@@ -340,7 +340,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
           // alpha = min(0.99, o G) >= 1/255  <=>  o G >= 1/255: the clamp is applied after the mask (one select fewer); the
           // decision is the forward's bit for bit
           const bool valid = idx < last && p2 <= 0.0f && oG >= (1.0f / 255.0f);
-          float cg = c.x * gC0 + c.y * gC1 + c.z * gC2 + c.w * gD;
+          // (a chain of plain fmas: paired into v_pk_mul_f32 + adds -- what the compiler makes of the sum of products -- it costs more
+          // cycles, a packed operation being worth 1.2 plain ones here, and needs its operands moved into register pairs)
+          float cg = __builtin_fmaf(c.x, gC0, __builtin_fmaf(c.y, gC1, __builtin_fmaf(c.z, gC2, c.w * gD)));
           asm volatile("" : "+v"(cg));  // (c . g is formed HERE, not sunk into the branch below: the colour registers are free for the next row)
           c = rec[jj * REC_F4 + 2];
           if (__builtin_amdgcn_ballot_w64(valid) != 0ull) {
@@ -352,6 +354,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
             asm("v_min_f32 %0, 0x3f7d70a4, %1" : "=v"(alpha) : "v"(oGm));
             const float inv1ma = __builtin_amdgcn_rcpf(1.f - alpha);
             T = T * inv1ma;  // T <- T / (1 - alpha)
+            asm volatile("" : "+v"(T));  // (on its own: not paired with Tf_bg * inv1ma, which would cost two register moves)
             // dL/dalpha needs accum_rec only through its product with this pixel's seeds, sum_ch (c_ch - accum_rec_ch) g_ch
             // (backward.cu:799-823, colour and depth alike): the four recurrences accum_rec <- alpha c + (1 - alpha) accum_rec
             // collapse into ONE for the scalar s = accum_rec . g, s <- s + alpha (c . g - s) -- 6 VALU operations per entry
@@ -360,7 +363,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
             const float dL_dalpha = dd * T - Tf_bg * inv1ma;
             accS += alpha * dd;
             // w = dL/dG * G = (o dL/dalpha) G (backward.cu:826-829; G, not the clamped alpha): o G is at hand from the alpha test
-            wu[nslot * WU_STRIDE + lane] = make_float2(dL_dalpha * oGm, alpha * T);
+            float w_ = dL_dalpha * oGm;
+            asm volatile("" : "+v"(w_));  // (two plain multiplies into a register pair, not v_pk_mul_f32 of operands moved into pairs)
+            wu[nslot * WU_STRIDE + lane] = make_float2(w_, alpha * T);
             slot_pack |= (unsigned long long)j << (8 * nslot);
             nslot++;
             if (nslot == SLOTS) flush();
