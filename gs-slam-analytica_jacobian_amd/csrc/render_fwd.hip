@@ -223,6 +223,9 @@ __global__ __launch_bounds__(GSAJ_FWD_THREADS) __attribute__((amdgpu_waves_per_e
             counting = hB != 0ull;
           }
         }
+        // (not before this point: requested earlier, while the first pair still occupies these registers, the next pair lands in others
+        // and is copied over at the end of the step -- six moves per step)
+        asm volatile("" : "+v"(T), "+v"(last), "+v"(Crg), "+v"(Cbd) : : "memory");  // (the first pair's results are formed: its registers are free)
         a0 = rec[pb + 12], a1 = rec[pb + 13], a2 = rec[pb + 14], a3 = rec[pb + 15], a4 = rec[pb + 16];
         a5 = rec2[(pb + 17) * 2];
         {
