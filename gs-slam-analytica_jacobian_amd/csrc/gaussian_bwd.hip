@@ -554,16 +554,33 @@ int launch_gaussian_backward(const BwdParams &p, const GeomWS &g, const BinWS &b
 //  k_chain_window + k_tau_sum: below.
 // one step of the keyed wave scan: lanes that receive a value through the DPP pattern CTRL (row mask ROWS) add it iff it comes from
 // the same owner; lanes the pattern does not reach see the key -1 and add nothing
+// Each value and step is ONE v_fmac_f32 with a DPP operand: v += dpp(v) * same, same = 1.0 where the incoming value is the lane's own
+// owner's, else 0.0 (sums are finite, so x * 0 = 0 and x * 1 + v is the add, bit for bit); a lane the pattern does not reach is not
+// written (bound_ctrl off).  As "v += same ? dpp(v) : 0" every value and step cost a zero initialisation, a DPP move, a select and an
+// add, and the kernel was as VALU-bound (0.71) as it was HBM-bound.  (Masking the adds with EXEC instead does not work: a DPP read
+// of a lane that EXEC disables is an invalid read, and the lanes to be skipped are other lanes' sources.)
+#define GSAJ_SCAN_STEP(DPPSTR)                                                                                          \
+  asm volatile("v_fmac_f32_dpp %[v0], %[v0], %[m] " DPPSTR "\n\tv_fmac_f32_dpp %[v1], %[v1], %[m] " DPPSTR "\n\t"           \
+               "v_fmac_f32_dpp %[v2], %[v2], %[m] " DPPSTR "\n\tv_fmac_f32_dpp %[v3], %[v3], %[m] " DPPSTR "\n\t"           \
+               "v_fmac_f32_dpp %[v4], %[v4], %[m] " DPPSTR "\n\tv_fmac_f32_dpp %[v5], %[v5], %[m] " DPPSTR "\n\t"           \
+               "v_fmac_f32_dpp %[v6], %[v6], %[m] " DPPSTR "\n\tv_fmac_f32_dpp %[v7], %[v7], %[m] " DPPSTR "\n\t"           \
+               "v_fmac_f32_dpp %[v8], %[v8], %[m] " DPPSTR "\n\tv_fmac_f32_dpp %[v9], %[v9], %[m] " DPPSTR                   \
+               : [v0] "+v"(v[0]), [v1] "+v"(v[1]), [v2] "+v"(v[2]), [v3] "+v"(v[3]), [v4] "+v"(v[4]), [v5] "+v"(v[5]),       \
+                 [v6] "+v"(v[6]), [v7] "+v"(v[7]), [v8] "+v"(v[8]), [v9] "+v"(v[9])                                          \
+               : [m] "v"(same))
 template <int CTRL, int ROWS>
 __device__ __forceinline__ void scan_by_key_step(int own, float (&v)[10]) {
   const int own_in = __builtin_amdgcn_update_dpp(-1, own, CTRL, ROWS, 0xF, false);
-  const bool same = own_in == own;
-#pragma unroll
-  for (int c = 0; c < 10; c++) {
-    const float in = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[c]), CTRL, ROWS, 0xF, false));
-    v[c] += same ? in : 0.f;
-  }
+  const float same = own_in == own ? 1.0f : 0.0f;
+  static_assert(CTRL == 0x111 || CTRL == 0x112 || CTRL == 0x114 || CTRL == 0x118 || CTRL == 0x142 || CTRL == 0x143, "the six steps of the wave scan");
+  if constexpr (CTRL == 0x111) GSAJ_SCAN_STEP("row_shr:1 row_mask:0xf bank_mask:0xf");
+  else if constexpr (CTRL == 0x112) GSAJ_SCAN_STEP("row_shr:2 row_mask:0xf bank_mask:0xf");
+  else if constexpr (CTRL == 0x114) GSAJ_SCAN_STEP("row_shr:4 row_mask:0xf bank_mask:0xf");
+  else if constexpr (CTRL == 0x118) GSAJ_SCAN_STEP("row_shr:8 row_mask:0xf bank_mask:0xf");
+  else if constexpr (CTRL == 0x142) GSAJ_SCAN_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf");
+  else GSAJ_SCAN_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf");
 }
+#undef GSAJ_SCAN_STEP
 
 // k_gather_sums: lane = ROW.  A wave owns 64 consecutive Gaussians, whose instance rows are ONE contiguous block ordered by
 // owner; it walks the block 64 rows at a time with fully coalesced loads (row + `reached` flag requested together: one memory
