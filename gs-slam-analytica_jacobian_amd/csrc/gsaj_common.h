@@ -130,9 +130,14 @@ struct ViewStrides {
   size_t geom, image, bin;  // bytes between consecutive views' workspaces
 };
 #ifdef __HIPCC__
+#include <type_traits>
 template <typename T>
 __device__ __forceinline__ T *gsaj_shift(T *p, size_t bytes) {
-  return reinterpret_cast<T *>(reinterpret_cast<uintptr_t>(p) + bytes);
+  // (pointer arithmetic, not integer arithmetic: through an integer the compiler loses track of where the pointer came from, takes it
+  // for a generic pointer, and every load through it becomes a FLAT load -- counted by the LDS counter too, so that a wait for an LDS
+  // read also waits for the rows requested chunks ahead)
+  typedef typename std::conditional<std::is_const<T>::value, const char, char>::type byte_t;
+  return reinterpret_cast<T *>(reinterpret_cast<byte_t *>(p) + bytes);
 }
 __device__ __forceinline__ GeomWS geom_view(GeomWS g, size_t off) {
   g.depths = gsaj_shift(g.depths, off); g.cov3D = gsaj_shift(g.cov3D, off); g.clamped = gsaj_shift(g.clamped, off);
