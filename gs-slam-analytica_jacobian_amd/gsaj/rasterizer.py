@@ -407,7 +407,8 @@ class FrameContext:
                 self.n_touched.data_ptr(), self.geom.data_ptr(), self.binning.data_ptr(), self.binning.numel(),
                 self.capacity, self.tile_list_capacity, self.img.data_ptr(), self.flags, st), "gsaj_rasterize_forward_async")
             self.R = self.capacity  # what the backward must be given (arena carving)
-            self.watch.post()
+            if self.auto_grow:
+                self.watch.post()
             return self.R
         _lib.check(lib.gsaj_forward_preprocess(
             self.P, int(sh_degree), self.M, self.W, self.H, _ptr(means3D), _ptr(shs), _ptr(colors_precomp),
@@ -452,7 +453,8 @@ class FrameContext:
                 float(loss["rgb_boundary_threshold"]), _ptr(loss["gt_color"]), _ptr(loss.get("gt_depth")), _ptr(loss.get("grad_mask")),
                 _ptr(loss.get("exposure_a")), _ptr(loss.get("exposure_b")), loss["scalars"].data_ptr(), self.loss_ws.data_ptr(),
                 _stream(self.dev)), "gsaj_rasterize_forward_loss")
-            self.watch.post()
+            if self.auto_grow:
+                self.watch.post()
         self.R = self.capacity
         return self.R
 
@@ -650,7 +652,8 @@ class BatchContext:
                     self.tile_list_capacity = min(SORT_CAP, int(1.1 * seen[1]) + 1)
         self._launch(*a)
         if not sync:
-            self.watch.post()
+            if self.auto_grow:
+                self.watch.post()
             return None
         st = self.status()
         if any(ab for _, _, ab in st):
@@ -661,6 +664,12 @@ class BatchContext:
             st = self.status()
             if any(ab for _, _, ab in st):
                 raise _lib.GsajError("the batch was aborted again after re-sizing the arena to %d instances per view: %r" % (self.capacity, st))
+        if self.auto_grow and max(r for r, _, _ in st) > self.watch.grow_at * self.capacity:
+            # the window fits, but with less head room than the arena watch keeps: re-size HERE, where blocking is allowed, rather than
+            # a few asynchronous windows later (an allocation of gigabytes in the middle of a loop)
+            self._size(int(1.5 * max(r for r, _, _ in st)) + 1024)
+            self._launch(*a)
+            st = self.status()
         self.tile_list_capacity = min(SORT_CAP, max(self.tile_list_capacity, int(1.1 * max(m for _, m, _ in st)) + 1, 256))
         return st
 

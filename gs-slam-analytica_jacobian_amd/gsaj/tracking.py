@@ -151,7 +151,8 @@ class DeviceTracker:
                     if self._graphs is None or self._graphs[2] != self.ctx.binning.data_ptr():
                         self._capture()  # (again if the arena was re-allocated: the graph holds its address)
                     self._graphs[0].replay()
-                    self.ctx.watch.post()
+                    if self.ctx.auto_grow:
+                        self.ctx.watch.post()
                     if self._graphs[1] is not None:
                         tbs.allreduce_pose_terms(self.packed, self.group)
                         self._graphs[1].replay()
