@@ -39,8 +39,9 @@ import numpy as np  # noqa: E402
 FLOP_FWD, FLOP_BWD = 24.0, 87.0  # fp32 flop per interaction (+ 1 exp fwd, 1 exp + 1 rcp bwd)
 PEAK_FP32_TFLOPS = 157.3         # MI355X fp32 vector peak (MI355X_MICROARCH.md; equals the fp32 MFMA dense peak)
 PEAK_HBM_GBS = 8000.0
-PRIMING_STEPS = 3                # untimed, before --warmup: window 1 sizes the binning arenas synchronously, window 2 is the first
-                                 # asynchronous one, and a fresh box has spent tens of ms in its first launches
+PRIMING_STEPS = 24  # untimed windows before the warm-up the command line asks for: the first sizes the arenas (synchronous), the next
+                    # load every code object, and the GPU needs ~15 ms of work to reach its steady clocks (20 timed windows after
+                    # 8 untimed ones ran 6 % slower than after 30); reported as priming_steps, never counted as warm-up
 PMC_FILE = "profiles/r03_pmc_summary.json"
 
 

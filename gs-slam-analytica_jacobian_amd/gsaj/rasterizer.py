@@ -6,6 +6,7 @@ PyTorch only provides device memory and the current HIP stream here; every compu
 happens in the hand-written kernels.
 """
 import ctypes
+import os
 
 import torch
 
@@ -268,6 +269,12 @@ class ArenaWatch:
         self.event = torch.cuda.Event()
         self.pending, self.calls = False, 0
         self.grown = 0  # how many times the arena was re-allocated ahead of an overflow
+        # the very first strided device-to-pinned-host copy costs tens of milliseconds (the copy kernel's code object is loaded
+        # lazily): paid here, where blocking is allowed, not in the middle of somebody's loop
+        with torch.cuda.device(img.device):
+            self.host.copy_(self.dev_counters, non_blocking=True)
+            self.event.record()
+            self.event.synchronize()
 
     def post(self):
         """After an asynchronous forward was enqueued."""
@@ -311,7 +318,7 @@ class FrameContext:
         self.tile_list_capacity = 0  # tile-list length the LDS sort of asynchronous frames is sized for (0: the maximum, 16384);
                                      # a longer list is sorted in chunks + merge passes (slower, never wrong)
         self.watch = ArenaWatch(self.img, 1, self.img.numel(), self.abort_flag_ptr() - 16 - self.img.data_ptr())  # (counters[4] = the abort word)
-        self.auto_grow = True  # asynchronous frames: grow the arena ahead of an overflow (ArenaWatch)
+        self.auto_grow = os.environ.get("GSAJ_ARENA_WATCH", "1") != "0"  # asynchronous frames: grow the arena ahead of an overflow (ArenaWatch)
         # per-Gaussian parameter gradients live in ONE flat bucket (field-major) so that a multi-GPU
         # mapping step can all-reduce it with a single collective (gsaj.keyframe_shard); `grad_slots`
         # buckets let the collective of step i overlap the kernels of step i+1
@@ -547,7 +554,7 @@ class BatchContext:
         self.binning = torch.empty(0, **byte)
         self.capacity, self.tile_list_capacity, self.bin_stride = 0, 0, 0
         self.watch = ArenaWatch(self.img, self.K, self.img_stride, lib.gsaj_forward_abort_flag(W, H, self.img.data_ptr()) - 16 - self.img.data_ptr())
-        self.auto_grow = True  # sync=False windows: grow the arena ahead of an overflow (ArenaWatch)
+        self.auto_grow = os.environ.get("GSAJ_ARENA_WATCH", "1") != "0"  # sync=False windows: grow the arena ahead of an overflow (ArenaWatch)
         self.buckets, self.slots = [], []
         for _ in range(max(1, grad_slots)):
             bucket = torch.zeros(bucket_numel(P, M, has_scales, K * n_windows), **f)
