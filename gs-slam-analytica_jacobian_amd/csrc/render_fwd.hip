@@ -160,6 +160,7 @@ __global__ __launch_bounds__(GSAJ_FWD_THREADS) __attribute__((amdgpu_waves_per_e
       if (base + (uint32_t)lane < range.y) gsaj_load_row(splat, splat16, id_nxt, rec16, q0, q1, q2);
     };
     float *recf = reinterpret_cast<float *>(rec);
+    for (int i = lane; i < ((FWD_CHUNK + FWD_PAD) / 2) * FWD_PAIR_F4; i += 64) rec[i] = make_float4(0.f, 0.f, 0.f, 0.f);  // (see the sentinels below)
     // packed slot s -> pair s / 2, half s % 2 of the pair-interleaved layout (FWD_PAIR_F4 float4 per pair)
     auto put = [&](int s, float x, float y, float kx, float ky, float kz, float o, float4 c, uint32_t pos, uint32_t id) {
       const int h = s & 1, pb = (s >> 1) * FWD_PAIR_F4;
@@ -186,7 +187,9 @@ __global__ __launch_bounds__(GSAJ_FWD_THREADS) __attribute__((amdgpu_waves_per_e
         const float3 k = gsaj_prescale_conic(q1.x, q1.y, q1.z);
         put(slot, q0.x, q0.y, k.x, k.y, k.z, q1.w, make_float4(q2.x, q2.y, q2.z, q0.z), base - range.x + (uint32_t)lane + 1u, id_here);
       }
-      if (lane < FWD_PAD) put(nrel + lane, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, make_float4(0.f, 0.f, 0.f, 0.f), 0u, 0u);  // inert sentinels (opacity 0)
+      // inert sentinels behind the packed entries: opacity 0 is enough -- whatever else the slot holds is a finite number (an earlier
+      // entry's, or the zeros the area started with), so the entry's power is finite or positive, its alpha 0 or rejected, its weight 0
+      if (lane < FWD_PAD) recf[((nrel + lane) >> 1) * FWD_PAIR_F4 * 4 + 10 + ((nrel + lane) & 1)] = 0.f;
       fetch_row(base + FWD_CHUNK);
       fetch_id(base + 2 * FWD_CHUNK);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
