@@ -218,7 +218,7 @@ def run(a):
                     ks.exchange_gaussian_grads(ctx.buckets[0], form=form)
                 torch.cuda.synchronize(dev)
                 comm[form + "_ms"] = 1e2 * (time.perf_counter() - t1)
-            except (RuntimeError, NotImplementedError) as e:  # (gloo has no reduce-scatter)
+            except Exception as e:  # (gloo has no reduce-scatter; informational leg, outside the timed region: never fatal)
                 comm[form + "_ms"] = None
                 comm[form + "_error"] = str(e).splitlines()[0][:120]
         fence()
