@@ -852,13 +852,19 @@ __device__ const uint64_t *sort_long_list(uint64_t *lds, int T, uint32_t *split_
                                           uint64_t *a, uint64_t *b, int n, int tid) {
   for (int c0 = 0; c0 < n; c0 += T) {
     const int len = min(T, n - c0);
-    for (int i = tid; i < T; i += NT) {
-      uint64_t key = KEY_INF;
-      if (i < len) {
-        const uint32_t id = ids[c0 + i];
-        key = ((uint64_t)__float_as_uint(depths[id]) << 32) | id;
+    for (int i0 = tid; i0 < T; i0 += 4 * NT) {  // (four ids, then four depths, in flight together: k_tile_sort)
+      uint32_t id[4], dz[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) id[u] = ids[c0 + min(i0 + u * NT, len - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; u++) dz[u] = __float_as_uint(depths[id[u]]);
+#pragma unroll
+      for (int u = 0; u < 4; u++) asm volatile("" : "+v"(dz[u]));
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int i = i0 + u * NT;
+        if (i < T) lds[i] = i < len ? ((uint64_t)dz[u] << 32) | id[u] : KEY_INF;
       }
-      lds[i] = key;
     }
     __syncthreads();
     lds_bitonic_sort<NT>(lds, T, tid);
@@ -974,13 +980,21 @@ __global__ __launch_bounds__(NT) void k_tile_sort(ImageWS im, const float *__res
     if (pass == 2 && m > cap) return;       // pass 1's (here cap = half of pass 1's)
     // the tile's ids as scattered (point_list, sorted in place below) + their depths gathered from the 4-byte depth array (L2)
     const int nup = ((n + 127) >> 7) << 7;  // (KEY_INF up to the end of the last 128-key chunk: lds_bitonic_sort)
-    for (int i = tid; i < nup; i += NT) {
-      uint64_t key = KEY_INF;
-      if (i < n) {
-        const uint32_t id = point_list[beg + i];
-        key = ((uint64_t)__float_as_uint(depths[id]) << 32) | id;
+    // Four ids, then their four depths, in flight together: one entry at a time the two dependent loads of every trip were
+    // most of a short list's life (a position past the list reads the list's last entry and stores KEY_INF).
+    for (int i0 = tid; i0 < nup; i0 += 4 * NT) {
+      uint32_t id[4], dz[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) id[u] = point_list[beg + (uint32_t)min(i0 + u * NT, n - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; u++) dz[u] = __float_as_uint(depths[id[u]]);
+#pragma unroll
+      for (int u = 0; u < 4; u++) asm volatile("" : "+v"(dz[u]));  // (all eight loads issued HERE, not sunk into the branches below)
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int i = i0 + u * NT;
+        if (i < nup) keys[i] = i < n ? ((uint64_t)dz[u] << 32) | id[u] : KEY_INF;
       }
-      keys[i] = key;
     }
     __syncthreads();
 #ifdef GSAJ_BLOCK_TRACE
