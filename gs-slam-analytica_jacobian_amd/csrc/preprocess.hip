@@ -468,13 +468,15 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_frame_scan(int nblk, int tiles, i
 #define SCAT_CLS 8
 #endif
 #define SCAT_LDS_TILES 4096  // class-local tiles the LDS counters hold (3 words each: 48 KB); more: direct global atomics
-#define SCAT_STAGE 4096      // instances a workgroup stages in LDS before writing them out (32 KB); more: stored directly
+#define SCAT_STAGE 4096      // instances a workgroup stages in LDS before writing them out (16 KB of ids + 8 KB of 16-bit tile indices: six
+                             // workgroups per CU; with the 32-bit slot staged beside the id: 32 KB, four); more: stored directly
 GSAJ_TRACE_DEFINE(scat)
 
 __global__ __launch_bounds__(PRE_BLOCK) void k_scatter_instances(int P, int gx, int gy, int gpt, GeomWS g, ImageWS im,
                                                                  uint32_t *__restrict__ inst_id, ViewStrides vs) {
   extern __shared__ uint32_t lds[];  // [3 * ltiles]: count -> reserved base, fill cursor, staging base (class-local tile index)
-  __shared__ uint32_t stage_id[SCAT_STAGE], stage_slot[SCAT_STAGE];
+  __shared__ uint32_t stage_id[SCAT_STAGE];
+  __shared__ uint16_t stage_lt[SCAT_STAGE];  // class-local tile of a staged id (its slot = the tile's reserved base + position in the tile's run)
   __shared__ uint32_t s_wave[PRE_BLOCK / 64], s_carry;
   {
     const size_t view = blockIdx.y;
@@ -574,10 +576,13 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scatter_instances(int P, int gx, 
     SCAT_FOR_EACH_TILE({
       const uint32_t k = atomicAdd(&fill[lt], 1u);
       stage_id[lbase[lt] + k] = id;
-      stage_slot[lbase[lt] + k] = cnt[lt] + k;
+      stage_lt[lbase[lt] + k] = (uint16_t)lt;
     })
     __syncthreads();
-    for (uint32_t i = tid; i < total; i += PRE_BLOCK) inst_id[stage_slot[i]] = stage_id[i];
+    for (uint32_t i = tid; i < total; i += PRE_BLOCK) {
+      const uint32_t lt = stage_lt[i];
+      inst_id[cnt[lt] + (i - lbase[lt])] = stage_id[i];
+    }
   } else {  // (large Gaussians: more instances than the staging area holds)
     SCAT_FOR_EACH_TILE({ inst_id[cnt[lt] + atomicAdd(&fill[lt], 1u)] = id; })
   }
@@ -1077,6 +1082,12 @@ int launch_tile_binning(int P, int sort_cap, int rec16, int grid_x, int grid_y, 
     // 64-byte pieces leave L2
     int gpt = 4;
     while (gpt < 8 && (long long)P * views * SCAT_CLS / ((long long)PRE_BLOCK * gpt * 2) >= 1536) gpt *= 2;
+    // (a launch that misses ONE resident generation -- 6 workgroups x 256 CUs -- by a few workgroups: one or two more blocks each)
+    for (int g2 = 9; gpt == 8 && g2 <= 10; g2++) {
+      const long long wg8 = (long long)((P + PRE_BLOCK * 8 - 1) / (PRE_BLOCK * 8)) * SCAT_CLS * views;
+      const long long wg2 = (long long)((P + PRE_BLOCK * g2 - 1) / (PRE_BLOCK * g2)) * SCAT_CLS * views;
+      if (wg8 > 1536 && wg2 <= 1536) gpt = g2;
+    }
     const int per = PRE_BLOCK * gpt;
     hipLaunchKernelGGL(k_scatter_instances, dim3((unsigned)((P + per - 1) / per) * SCAT_CLS, views), dim3(PRE_BLOCK), lds, s, P, grid_x,
                        grid_y, gpt, g, im, b.point_list, vs);
