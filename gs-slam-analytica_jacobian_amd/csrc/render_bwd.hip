@@ -16,9 +16,9 @@
 //      d/dmean2D ~ w * (conic . d),  d/dconic ~ w * d d^T,  d/dopacity = w / o,  d/dcolour = u * dL/dC,
 //      d/ddepth = u * dL/dD.        (w, u) go to LDS, one 64-pixel row per entry.
 //  phase 2 (lane = (entry slot, pixel row)):  8 slots x 8 pixel rows = 64 lanes.  Each lane walks
-//    the 8 pixels of its row with three running sums of w (1, x', x'^2 about the quadrant's centre
-//    column -- dy is constant along a row and dx = ax - x', so these give every second moment about
-//    the Gaussian's mean) and the 4 products u * seed; the 8 rows of a slot are then combined with
+//    the 8 pixels of its row with three running sums -- w, w dx, w dx^2, dx the pixel's own distance
+//    from the Gaussian's mean; dy is constant along a row, so these give every second moment about
+//    the mean -- and the 4 products u * seed; the 8 rows of a slot are then combined with
 //    three register-merge steps (v_permlane32_swap, v_permlane16_swap, one DPP rotation) -- against
 //    ~29 cross-lane instructions (~80 plain-VALU issue slots, measured) for reducing the 10 partials
 //    of every entry across the wave directly.
@@ -256,33 +256,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         tr_flushes++;
         tr_slots += (unsigned)nslot;
 #endif
-        // Lane (slot s, pixel row y): the row's 8 pixels sit at x' = -3.5 .. 3.5 around the quadrant centre column, so
-        // three running sums of w (1, x', x'^2) give every second moment of the row about the Gaussian's mean:
-        // dx = ax - x' (ax = mean x - centre column), dy constant along the row.  Slots beyond nslot hold stale rows;
-        // slots never mix, and only live ones are stored.
+        // Lane (slot s, pixel row y): three running sums over the row's 8 pixels -- w, w dx, w dx^2 with every pixel's OWN
+        // dx = mean x - pixel x -- give every second moment of the row about the Gaussian's mean (dy is constant along the
+        // row).  (Moments about the quadrant's centre column -- sums of w x', w x'^2 with compile-time x', shifted to the mean
+        // afterwards -- are two operations per pixel cheaper, but the shift cancels: a Gaussian whose only contributing pixel
+        // sits 0.01 px from its mean had sum w dx^2 wrong in the third digit -- 12 eps sum|w| against a sum of 1.5e-4 |w|.)
+        // Slots beyond nslot hold stale rows; slots never mix, and only live ones are stored.
         const int j = (int)((slot_pack >> (8 * p2_slot)) & 0xffull);
         const float4 e0 = rec[j * REC_F4 + 0];
         float4 e1 = rec[j * REC_F4 + 1];
         e1.x *= -2.0f / GSAJ_LOG2E; e1.y *= -1.0f / GSAJ_LOG2E; e1.z *= -2.0f / GSAJ_LOG2E;  // pre-scaled conic -> (a, b, c)
-        const float ax = e0.x - (qx0 + 3.5f), dy = e0.y - p2_py;
-        float m0 = 0.f, m1 = 0.f, m2 = 0.f, u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f;
+        const float ax0 = e0.x - qx0, dy = e0.y - p2_py;  // (mean x relative to the row's first pixel: exact, or as well conditioned as dx itself)
+        float m0 = 0.f, swdx = 0.f, swdx2 = 0.f, u0 = 0.f, u1 = 0.f, u2 = 0.f, u3 = 0.f;  // sum w, sum w dx, sum w dx^2
 #pragma unroll
         for (int it = 0; it < 8; it++) {
           const int pix = p2_row * 8 + it;
           const float2 q = wu[p2_slot * WU_STRIDE + pix];
           const float4 sd = seed[pix];
-          const float xc = (float)it - 3.5f;
+          const float dx = ax0 - (float)it;  // the pixel's own dx, as phase 1 and the reference form it (backward.cu:736)
+          const float wd = q.x * dx;
           m0 += q.x;
-          m1 += q.x * xc;
-          m2 += q.x * (xc * xc);
+          swdx += wd;
+          swdx2 = __builtin_fmaf(wd, dx, swdx2);
           u0 += q.y * sd.x;
           u1 += q.y * sd.y;
           u2 += q.y * sd.z;
           u3 += q.y * sd.w;
         }
-        const float swdx = ax * m0 - m1;               // sum w dx
         const float swdy = dy * m0;                    // sum w dy
-        const float swdx2 = ax * (swdx - m1) + m2;     // sum w dx^2 = ax (ax m0 - 2 m1) + m2
         // the 10 partials are linear in the moments: convert per pixel row, then combine the 8 rows
         float v[10];
         v[0] = -(e1.x * swdx + e1.y * swdy) * ddelx_dx;  // dL/dmean2D.x  (dG/ddx = -G (a dx + b dy))

@@ -91,7 +91,15 @@ def _fuzz_case(seed):
     return P, W, H, deg, cam, sc, bg, bits
 
 
-@pytest.mark.parametrize("seed", range(5000, 5064))
+def _fuzz_seeds():
+    """The suite's 64 seeds; GSAJ_FUZZ_RANGE=lo:hi runs another range (a soak run after a change to the binning kernels)."""
+    import os
+
+    lo, hi = (int(x) for x in os.environ.get("GSAJ_FUZZ_RANGE", "5000:5064").split(":"))
+    return range(lo, hi)
+
+
+@pytest.mark.parametrize("seed", _fuzz_seeds())
 def test_fuzz_parity(seed):
     """tools/fuzz_parity.py as a test: one random scene / camera / option set per seed (64 seeds; 5052 is the seed whose
     single borderline pixel once widened the image budget -- that pixel is now verified to BE borderline)."""
