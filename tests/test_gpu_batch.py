@@ -51,7 +51,13 @@ def _run(K, cams, sc, deg, precomp=False, record_bits=32, seed=50, streams=1):
     return bc, g, st, singles, (dLc, dLd)
 
 
-def _compare(bc, g, st, singles, precomp):
+def _compare(bc, g, st, singles, precomp, fuzz=False):
+    """fuzz: random windows (test_batch_fuzz).  Their dL/dtau sums may cancel (|sum| far below the sum of the |rows|) and their
+    chains meet ill-conditioned rows (needle-shaped Gaussians: scale ranges up to e^3, cf. layer (B) of
+    helpers.assert_grads_close), on which two fp32 evaluations differ by far more than on the fixed scenes: every tolerance is
+    ten times the fixed scenes', and the sum of the rows is also allowed 2e-5 of the sum of the |rows|.  (Soak run, seeds
+    9000-11999: 8 of the first 1000 windows exceed the fixed tolerances, by at most 4.5x; ONE of the 3000 -- seed 11011 -- exceeds
+    these on a single per-Gaussian dL/dtau row, by 1.2x.  A wrong row, view or sum is off by orders of magnitude.)"""
     import torch
 
     K = bc.K
@@ -65,14 +71,17 @@ def _compare(bc, g, st, singles, precomp):
         for a, b, nm in ((g["mean2D"][k], gs["mean2D"], "mean2D"), (g["tau"][k], gs["tau"], "tau"), (g["tau_all"][k], gs["tau_sum"], "tau_sum")):
             # (the per-Gaussian dL/dtau rows: the batched chain reads the SH coefficients from memory where the single-view kernel
             # stages them in LDS -- two instantiations of the view-direction term, which the compiler contracts differently)
-            assert float((a - b).abs().max()) <= (3e-5 if nm == "tau" else 3e-6) * float(b.abs().max()), "per-view dL/d%s differs" % nm
+            allowed = (3e-5 if nm == "tau" else 3e-6) * float(b.abs().max()) * (10.0 if fuzz else 1.0)
+            if fuzz and nm == "tau_sum":
+                allowed += 2e-5 * float(gs["tau"].abs().sum(dim=0).max())
+            assert float((a - b).abs().max()) <= allowed, "per-view dL/d%s differs" % nm
     names = ["mean3D", "opacity", "cov3D"] if precomp else ["mean3D", "opacity", "sh", "scale", "rot"]
     for n in names:
         want = sum(s[1][n].double() for s in singles)
         e = float((g[n].double() - want).abs().max() / want.abs().max())
         # K terms, each within the chain's fp32 rounding (cf. */chain_row in parity_errors.jsonl), summed in view order; dL/dscale and
         # dL/drot are formed from the SUMMED dL/dcov3D (differences of its products: the rounding of the sum is amplified)
-        assert e < (1e-4 if n in ("scale", "rot") else 3e-5), (n, e)
+        assert e < (1e-4 if n in ("scale", "rot") else 3e-5) * (10.0 if fuzz else 1.0), (n, e)
 
 
 @pytest.mark.parametrize("K,precomp,bits,streams", [(3, False, 32, 1), (5, True, 32, 2), (8, False, 16, 2), (11, False, 32, 1), (2, False, 32, 2)])
@@ -252,3 +261,31 @@ def test_bucket_gradients_through_the_activations_equal_autograd_on_the_drop_in(
     # accumulate=True: a second window adds up
     model.assign_bucket_gradients(g, accumulate=True)
     assert float((model._xyz.grad - 2 * want[0]).abs().max() / want[0].abs().max()) < 4e-5
+
+
+def _batch_fuzz_seeds():
+    """Six seeds in the suite; GSAJ_BATCH_FUZZ_RANGE=lo:hi runs another range (a soak run after a change to the batched kernels)."""
+    import os
+
+    lo, hi = (int(x) for x in os.environ.get("GSAJ_BATCH_FUZZ_RANGE", "9000:9006").split(":"))
+    return range(lo, hi)
+
+
+@pytest.mark.parametrize("seed", _batch_fuzz_seeds())
+def test_batch_fuzz(seed):
+    """One random window per seed -- Gaussian count, image size, number of keyframes, SH storage, scale and opacity ranges, row
+    format -- through the batched entry points and, view by view, through the single-view ones: same images and counts bit for bit,
+    same gradients to fp32 rounding (_compare)."""
+    rng = np.random.default_rng(seed)
+    P, W, H, K = int(rng.integers(1, 3000)), int(rng.integers(17, 260)), int(rng.integers(17, 200)), int(rng.integers(1, 10))
+    coeffs = (1, 4, 9, 16)[int(rng.integers(0, 4))]
+    deg = int(rng.integers(0, int(round(coeffs ** 0.5))))
+    cam0 = hp.small_camera(W, H, f=float(rng.uniform(0.5, 1.5)) * W, orthonormal=True)
+    lo = float(np.log(rng.uniform(0.002, 0.05)))
+    olo = float(rng.uniform(0.004, 0.9))
+    sc = syn.make_scene(P, seed, cam0, z_range=(float(rng.uniform(0.3, 1.0)), float(rng.uniform(1.5, 8.0))),
+                        log_scale_range=(lo, lo + float(rng.uniform(0.5, 3.0))), opacity_range=(olo, min(1.0, olo + float(rng.uniform(0.05, 0.6)))),
+                        sh_coeffs=coeffs, margin=float(rng.uniform(0.0, 0.4)))
+    cams = syn.keyframe_cameras(K, radius=float(rng.uniform(0.05, 0.4)), W=W, H=H, fx=cam0["fx"], fy=cam0["fy"], cx=cam0["cx"], cy=cam0["cy"])
+    bc, g, st, singles, _ = _run(K, cams, sc, deg, record_bits=16 if seed % 5 == 4 else 32, seed=seed)
+    _compare(bc, g, st, singles, False, fuzz=True)
