@@ -121,3 +121,32 @@ def test_fuzz_parity(seed):
     hp.assert_image_close(depth.cpu().numpy(), ref["depth"], hp.IMG_TOL, st=st, tag=tag + "/depth")
     dLc, dLd = hp.seeds(cam, seed=seed)
     g, gref = hp.check_backward(cam, deg, out, args, st, dLc, dLd, tag)
+
+
+def test_equal_depths_keep_index_order():
+    """Every Gaussian four times (ids i, i + 300, i + 600, i + 900: identical depth bits): the reference's stable radix sort of
+    (tile | depth) keys leaves equal keys in emission order, i.e. ascending Gaussian index (rasterizer_impl.cu:353-368, 70-111);
+    here the index is the low word of the sort key.  point_list must match the oracle bit for bit, ties included."""
+    from gsaj import rasterizer as C
+
+    W, H, deg = 150, 97, 1
+    cam = hp.small_camera(W, H, f=0.9 * W, orthonormal=True)
+    sc1 = syn.make_scene(300, 77, cam, z_range=(0.8, 3.0), log_scale_range=(math.log(0.01), math.log(0.15)), opacity_range=(0.05, 0.6),
+                         sh_coeffs=4, margin=0.2)
+    sc = {k: (np.concatenate([v] * 4, axis=0) if isinstance(v, np.ndarray) and v.shape[:1] == (300,) else v) for k, v in sc1.items()}
+    P = 1200
+    (ref, st), kw = hp.oracle_forward(cam, sc, deg)
+    out, args = hp.gpu_forward(cam, sc, deg, kw=kw)
+    R, color, radii, geom, binning, img, depth, opacity, n_touched = out
+    assert R == ref["num_rendered"] and R > 0
+    dbg = {k: v.cpu().numpy() for k, v in C.debug_export(P, R, W, H, geom, binning, img).items()}
+    pl = dbg["point_list"].astype(np.uint32)
+    np.testing.assert_array_equal(pl, st["point_list"])
+    np.testing.assert_array_equal(dbg["ranges"], st["ranges"])
+    # (the property itself, independent of the oracle: inside a tile's list the four copies of a Gaussian are adjacent and ascending)
+    beg, end = (int(x) for x in dbg["ranges"][np.argmax(dbg["ranges"][:, 1] - dbg["ranges"][:, 0])])
+    run = pl[beg:end].astype(np.int64)
+    assert (end - beg) % 4 == 0 and np.all(run[0::4] % 300 == run[3::4] % 300) and np.all(np.diff(run.reshape(-1, 4), axis=1) == 300)
+    hp.assert_image_close(color.cpu().numpy(), ref["color"], hp.IMG_TOL, st=st, tag="ties/color")
+    dLc, dLd = hp.seeds(cam, seed=77)
+    hp.check_backward(cam, deg, out, args, st, dLc, dLd, "ties")
