@@ -441,6 +441,11 @@ void gsaj_oracle_render_backward(int P, int W, int H, const int *ranges, const u
  *                      Gaussians, so ANY fp32 evaluation of alpha = o exp(power) has a relative error of a few eps * mag;
  *                      n = how many contributors the walk has already un-blended at that pixel: T is recovered by
  *                      repeated division T <- T / (1 - alpha) (backward.cu:779), each adding a rounding of its own;
+ *                      plus, for the six terms that carry dL/dalpha, (factor) * eps * (1 + n) * T * sum over the channels and
+ *                      the depth of (|c| + |accum_rec|) |dL/dC|: dL/dalpha is a sum of DIFFERENCES c - accum_rec
+ *                      (backward.cu:799-823), which behind nearly opaque layers of the same colour cancel to a small
+ *                      fraction of their operands -- every fp32 evaluation, this oracle's float recurrences included, rounds
+ *                      them at the size of the operands (a map painted in ONE colour: tools/fuzz_uniform.py);
  *   flip_budget[g,c] = sum over BORDERLINE pixels of |term(all borderline decisions taken one way) - term(taken the other
  *                      way)|, where a pixel is borderline if some entry's alpha is within (border_rel + 4 eps mag) of 1/255,
  *                      T(1-alpha) within the accumulated relative uncertainty of 1e-4, or power within its rounding of 0:
@@ -514,20 +519,26 @@ static void em_backward(const EMScene *sc, int beg, int end, float pxf, float py
     T = T / (1.f - alpha);
     ndiv += 1.0;
     float dchannel_dcolor = alpha * T, dL_dalpha = 0.0f;
-    double t[10];
+    double t[10], operands = 0.0;  /* sum |c| |dL/dC| + |accum_rec| |dL/dC| over the channels and the depth: what (c - accum_rec) rounds at */
     for (int ch = 0; ch < 3; ch++) {
       float c = sc->colors[3 * g + ch];
       accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
       last_color[ch] = c;
       dL_dalpha += (c - accum_rec[ch]) * dLdC[ch];
+      operands += (fabs((double)c) + fabs((double)accum_rec[ch])) * fabs((double)dLdC[ch]);
       t[6 + ch] = (double)(dchannel_dcolor * dLdC[ch]);
     }
     float depth = sc->depths[g];
     accum_rec_depth = last_alpha * last_depth + (1.f - last_alpha) * accum_rec_depth;
     last_depth = depth;
     dL_dalpha += (depth - accum_rec_depth) * dLdD;
+    operands += (fabs((double)depth) + fabs((double)accum_rec_depth)) * fabs((double)dLdD);
     t[9] = (double)(dchannel_dcolor * dLdD);
     dL_dalpha *= T;
+    /* |rounding of dL/dalpha| that is NOT proportional to |dL/dalpha|: c - accum_rec is a difference (behind nearly opaque layers
+     * of the same colour it cancels to a small fraction of its operands), accum_rec carries the roundings of the ndiv steps of
+     * its recurrence, and the background term is added to the sum */
+    const double dalpha_abs = eps * (1.0 + ndiv) * (operands * (double)T + fabs((double)((-T_final / (1.f - alpha)) * bg_dot)));
     last_alpha = alpha;
     dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
     float dL_dG = co[3] * dL_dalpha, gdx = G * dx, gdy = G * dy;
@@ -547,6 +558,14 @@ static void em_backward(const EMScene *sc, int beg, int end, float pxf, float py
       a[1] = adG * (fabs((double)(gdy * co[2])) + fabs((double)(gdx * co[1]))) * sc->ddely_dy;
       for (int c = 2; c < 10; c++) a[c] = fabs(t[c]);
       for (int c = 0; c < 10; c++) { mk[c] += a[c]; ck[c] += a[c] * eps * (1.0 + mag + ndiv); }
+      /* terms 0..5 are dL/dalpha times a factor: its absolute rounding (above) times that factor */
+      const double o = fabs((double)co[3]);
+      ck[0] += dalpha_abs * o * (fabs((double)(gdx * co[0])) + fabs((double)(gdy * co[1]))) * sc->ddelx_dx;
+      ck[1] += dalpha_abs * o * (fabs((double)(gdy * co[2])) + fabs((double)(gdx * co[1]))) * sc->ddely_dy;
+      ck[2] += dalpha_abs * o * 0.5 * fabs((double)(gdx * dx));
+      ck[3] += dalpha_abs * o * 0.5 * fabs((double)(gdx * dy));
+      ck[4] += dalpha_abs * o * 0.5 * fabs((double)(gdy * dy));
+      ck[5] += dalpha_abs * (double)G;
     }
   }
 }
