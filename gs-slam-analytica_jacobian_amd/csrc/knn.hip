@@ -284,7 +284,11 @@ __global__ __launch_bounds__(64) void k_knn_mean_dist(int P, KnnWS w, float *__r
       k_best3(dx * dx + dy * dy + dz * dz, b0, b1, b2);
     }
   }
-  const float reject = b2;  // an upper bound of the true 3rd-nearest distance (simple_knn.cu:165)
+  // an upper bound of the true 3rd-nearest distance (simple_knn.cu:165) -- with head room for rounding: the best three are
+  // found AGAIN below, and the neighbour that defines the bound may be a box of its own (the last, partial box: one point),
+  // whose box distance IS this bound up to the contraction of the two sums of squares; one ulp above it the box was skipped
+  // and the neighbour lost (tools/fuzz_knn.py, 2049 points)
+  const float reject = b2 * 1.000002f;
   b0 = FLT_MAX; b1 = FLT_MAX; b2 = FLT_MAX;
   const int nbox = (P + KNN_BOX - 1) / KNN_BOX;
   for (int b = 0; b < nbox; b++) {

@@ -82,3 +82,17 @@ def test_the_morton_sort_is_a_stable_sort_by_code(n, kind):
     key = {}
     for c, i in zip(codes[:5000], idx[:5000]):
         assert key.setdefault(tuple(p[i].astype(np.float32)), c) == c
+
+
+def test_a_neighbour_alone_in_the_last_box_is_not_lost():
+    """2049 points: the last 256-point box holds ONE point, and for its Morton neighbour that point is the third-nearest -- the one
+    that defines the search's rejection bound.  Its box distance equals the bound up to the contraction of two sums of squares; a
+    strict `>` on those skipped the box and lost the neighbour (found by tools/fuzz_knn.py, seed 173)."""
+    from oracle import knn_oracle
+
+    rng = np.random.default_rng(173)
+    n = int(rng.choice([4, 5, 63, 64, 65, 255, 256, 257, 1000, 2047, 2048, 2049, 4097, 6000]))
+    rng.integers(0, 5)
+    p = (rng.uniform(-1, 1, (n, 3)) * float(10 ** rng.uniform(-3, 3))).astype(np.float32)
+    assert n == 2049
+    np.testing.assert_allclose(_run(p), knn_oracle.dist2(p), rtol=2e-5, atol=0)
