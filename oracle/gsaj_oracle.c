@@ -451,7 +451,8 @@ void gsaj_oracle_render_backward(int P, int W, int H, const int *ranges, const u
  *                      T(1-alpha) within the accumulated relative uncertainty of 1e-4, or power within its rounding of 0:
  *                      there the cut-offs of forward.cu:406-535 may legitimately fall either way, and the whole pixel's
  *                      backward (this entry, the nearer ones through accum_rec, the farther ones through T, the last
- *                      contributor and T_final) is re-evaluated both ways, forward and backward.
+ *                      contributor and T_final) is re-evaluated, forward and backward, with the per-entry decisions and the
+ *                      termination decision each taken both ways (four outcomes); the budget is the spread of the term.
  *   border_mask[pix] = 1 for those pixels (the image / n_contrib checks allow differences only there).
  * All arrays are outputs; P-major [P,10] floats, border_mask [H*W] bytes. */
 typedef struct {
@@ -459,9 +460,12 @@ typedef struct {
   float ddelx_dx, ddely_dy, border_rel, border_rel_T;
 } EMScene;
 
-/* forward walk of one pixel with borderline decisions biased: +1 include / continue, -1 exclude / stop, 0 as computed.
- * Returns 1 if a borderline decision was met. */
-static int em_forward(const EMScene *sc, int beg, int end, float pxf, float pyf, int bias, float *T_out, int *last_out) {
+/* forward walk of one pixel with borderline decisions biased: `bias` for the per-entry tests (power <= 0, alpha >= 1/255: +1
+ * include, -1 exclude), `bias_stop` for the termination test (+1 continue, -1 stop), 0 as computed.  The two kinds are biased
+ * SEPARATELY: an entry at the alpha cut-off moves T by its (1 - alpha), i.e. by 0.4 %, and that can carry a termination test
+ * hundreds of entries later across 1e-4 -- "entry excluded, walk continued" is an outcome neither all-included nor
+ * all-excluded reaches (tests/test_gpu_random.py fuzz seed 8345).  Returns 1 if a borderline decision was met. */
+static int em_forward(const EMScene *sc, int beg, int end, float pxf, float pyf, int bias, int bias_stop, float *T_out, int *last_out) {
   const double eps = 1.1920929e-07, thr = 1.0 / 255.0;
   float T = 1.0f;
   int last = 0, border = 0;
@@ -483,7 +487,7 @@ static int em_forward(const EMScene *sc, int beg, int end, float pxf, float pyf,
     float test_T = T * (1 - alpha);
     t_rel += a_rel * alpha / (1.0 - alpha);
     int stop = test_T < 0.0001f;
-    if (fabs((double)test_T - 1e-4) <= t_rel * 1e-4) { border = 1; if (bias) stop = bias < 0; }
+    if (fabs((double)test_T - 1e-4) <= t_rel * 1e-4) { border = 1; if (bias_stop) stop = bias_stop < 0; }
     if (stop) break;
     T = test_T;
     last = k - beg + 1;
@@ -585,7 +589,7 @@ void gsaj_oracle_error_model(int P, int W, int H, const int *ranges, const uint3
   for (int tile = 0; tile < gx * gy; tile++) {
     const int ty = tile / gx, tx = tile - ty * gx;
     const int beg = ranges[2 * tile], end = ranges[2 * tile + 1], n = end - beg;
-    double *scratch = (double *)malloc(sizeof(double) * 10 * (size_t)(n > 0 ? n : 1) * 3);
+    double *scratch = (double *)malloc(sizeof(double) * 10 * (size_t)(n > 0 ? n : 1) * 4);
     double *v0 = scratch, *vp = scratch + 10 * (size_t)(n > 0 ? n : 1), *vm = vp + 10 * (size_t)(n > 0 ? n : 1);
     for (int py = ty * TILE; py < imin(H, (ty + 1) * TILE); py++)
       for (int px = tx * TILE; px < imin(W, (tx + 1) * TILE); px++) {
@@ -593,21 +597,27 @@ void gsaj_oracle_error_model(int P, int W, int H, const int *ranges, const uint3
         float dLdC[3] = {dL_dpix[pid], dL_dpix[(size_t)H * W + pid], dL_dpix[2 * (size_t)H * W + pid]};
         float dLdD = dL_dpix_depth[pid], Tf;
         int last;
-        const int border = em_forward(&sc, beg, end, (float)px, (float)py, 0, &Tf, &last);
+        const int border = em_forward(&sc, beg, end, (float)px, (float)py, 0, 0, &Tf, &last);
         border_mask[pid] = (uint8_t)border;
         if (n <= 0) continue;
         memset(v0, 0, sizeof(double) * 10 * (size_t)n);
         em_backward(&sc, beg, end, (float)px, (float)py, 0, Tf, last, dLdC, dLdD, v0, im + (size_t)beg * 10, ic + (size_t)beg * 10);
         if (border) {
-          float Tp, Tm;
-          int lp, lm;
-          memset(vp, 0, sizeof(double) * 10 * (size_t)n * 2);
-          em_forward(&sc, beg, end, (float)px, (float)py, +1, &Tp, &lp);
-          em_backward(&sc, beg, end, (float)px, (float)py, +1, Tp, lp, dLdC, dLdD, vp, NULL, NULL);
-          em_forward(&sc, beg, end, (float)px, (float)py, -1, &Tm, &lm);
-          em_backward(&sc, beg, end, (float)px, (float)py, -1, Tm, lm, dLdC, dLdD, vm, NULL, NULL);
-          for (size_t i = 0; i < (size_t)n * 10; i++)
-            ifl[(size_t)beg * 10 + i] += fmax(fabs(vp[i] - vm[i]), fmax(fabs(vp[i] - v0[i]), fabs(vm[i] - v0[i])));
+          /* the four outcomes (entries included / excluded) x (walk continued / stopped): per term, the spread of the five
+           * evaluations (running minimum and maximum in vp / vm) */
+          double *vc = scratch + 10 * (size_t)n * 3;
+          memcpy(vp, v0, sizeof(double) * 10 * (size_t)n);
+          memcpy(vm, v0, sizeof(double) * 10 * (size_t)n);
+          for (int combo = 0; combo < 4; combo++) {
+            const int ba = (combo & 1) ? +1 : -1, bs = (combo & 2) ? +1 : -1;
+            float Tc;
+            int lc;
+            memset(vc, 0, sizeof(double) * 10 * (size_t)n);
+            em_forward(&sc, beg, end, (float)px, (float)py, ba, bs, &Tc, &lc);
+            em_backward(&sc, beg, end, (float)px, (float)py, ba, Tc, lc, dLdC, dLdD, vc, NULL, NULL);
+            for (size_t i = 0; i < (size_t)n * 10; i++) { vp[i] = fmax(vp[i], vc[i]); vm[i] = fmin(vm[i], vc[i]); }
+          }
+          for (size_t i = 0; i < (size_t)n * 10; i++) ifl[(size_t)beg * 10 + i] += vp[i] - vm[i];
         }
       }
     free(scratch);
